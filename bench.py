@@ -1,0 +1,254 @@
+#!/usr/bin/env python
+"""Headline benchmark: train tokens/s of the speech-integration hot path (Llama-3.2-1B + 5000 HuBERT DSUs, SFT, bf16,
+seq_len 2048, batch 8 per GPU) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one optimizer step with gradient_accumulation_steps=1: micro-batch forward + backward (HIP kernels) ->
+[N>1: per-layer RCCL all-reduce overlapped with backward + one scalar all-reduce] -> fused scale+AdamW kernel.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line (contract in the task statement) with
+`roofline` (MFMA GEMM kernel family, HIP-event timed inside the timed region) and `cpu_baseline` (the CPU oracle timed on
+the host cores on a bounded sample; N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "speech-integration_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X (MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense")
+N_LAYERS_MM = 973_078_528  # matmul params per token in the 16 layers
+
+
+def flops_per_token(vocab: int, seq: int, dim: int = 2048, layers: int = 16) -> float:
+    """F_tok = 3 * [2 (N_layers_mm + D V) + 2 L D (S + 1)]  (fwd + 2x bwd, causal attention triangular)."""
+    return 3.0 * (2.0 * (N_LAYERS_MM + dim * vocab) + 2.0 * layers * dim * (seq + 1))
+
+
+class GemmTimer:
+    """HIP-event timing of every ssi_gemm launch inside the timed region (events on the stream the kernels run on)."""
+
+    def __init__(self):
+        self.records = []  # (layout, flops, start, end)
+        self.enabled = False
+
+    def install(self):
+        from ssi import ops
+        inner = ops.gemm
+        timer = self
+
+        def timed_gemm(layout, a, b, c, **kw):
+            if not timer.enabled:
+                return inner(layout, a, b, c, **kw)
+            M, N = c.shape
+            K = a.shape[1] if layout in (ops.GEMM_NT, ops.GEMM_NN) else a.shape[0]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            inner(layout, a, b, c, **kw)
+            e.record()
+            timer.records.append((layout, 2.0 * M * N * K, s, e))
+
+        ops.gemm = timed_gemm
+        import ssi.model as m
+        m.ops.gemm = timed_gemm
+
+    def summary(self):
+        tot_ms, tot_fl, per = 0.0, 0.0, {}
+        for layout, fl, s, e in self.records:
+            ms = s.elapsed_time(e)
+            tot_ms += ms
+            tot_fl += fl
+            d = per.setdefault(layout, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += ms
+            d[2] += fl
+        return tot_ms, tot_fl, per
+
+
+def cpu_baseline(seed: int) -> dict:
+    """CPU oracle (pure torch, fp32) timed on this host: config P of BASELINE.json (B=2, S=512, V=133 258, full 16-layer
+    1B model), one optimizer step = forward + backward + AdamW.  Bounded sample: 1 step (1024 tokens)."""
+    from oracle import step_oracle
+    from oracle.llama_oracle import OracleCEWithChunkedOutputLoss, build_oracle
+    from ssi.data import synthetic_batch
+    from ssi.llama_configs import configllama3_2_1b
+    import copy
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = copy.deepcopy(configllama3_2_1b)
+    cfg.n_dsus, cfg.modality_tokens = 5000, True
+    t0 = time.perf_counter()
+    model = build_oracle(cfg.parameters, dtype=torch.float32, seed=None, rope_cache_len=512)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("scale"):
+                p.fill_(1.0)
+            else:
+                p.normal_(0.0, 0.02)
+    model.set_num_output_chunks(8)
+    loss_fn = OracleCEWithChunkedOutputLoss()
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    batch = synthetic_batch(2, 512, 5000, seed=seed)
+    t_build = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    lb, n = step_oracle.train_step(model, loss_fn, batch)
+    step_oracle.optimizer_step(model, opt, n)
+    dt = time.perf_counter() - t1
+    tokens = batch["tokens"].numel()
+    return {"value": tokens / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"1 optimizer step (fwd+bwd+AdamW) of config P: B=2 x S=512 = {tokens} tokens, fp32, V=133258, 16 layers; "
+                      f"{dt:.1f} s step, {t_build:.1f} s model build (cold, no warm-up)", "loss": lb / max(n, 1)}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--n-dsus", type=int, default=5000)
+    ap.add_argument("--layers", type=int, default=16, help="debug only; the headline number needs 16")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+            return 2
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    import copy
+    from ssi.data import synthetic_batch
+    from ssi.distributed import GradSync, all_reduce_scalars, init_distributed
+    from ssi.llama_configs import configllama3_2_1b
+    from ssi.loss import CEWithChunkedOutputLoss, compute_loss
+    from ssi.model import HipLlamaDecoder
+    from ssi.optimizer import HipAdamW, scale_grads
+    from ssi.train_utils import count_token_types_async, get_token_type_ranges
+
+    init_distributed(device)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    lcfg = copy.deepcopy(configllama3_2_1b)
+    lcfg.n_dsus, lcfg.modality_tokens = args.n_dsus, True
+    lcfg.num_layers = args.layers
+    params = lcfg.parameters
+    torch.manual_seed(42_831)
+    model = HipLlamaDecoder(**params, dtype=dtype, device=device, rope_cache_len=max(args.seq, 2048))
+    with torch.no_grad():
+        model._flat.normal_(0.0, 0.02)
+        model._view("emb")[lcfg.vocab_size:].zero_()
+        for p, name, _ in model._param_src:
+            if name.endswith("norm"):
+                p.fill_(1.0)
+    model.train()
+    loss_fn = CEWithChunkedOutputLoss()
+    model.set_num_output_chunks(loss_fn.num_output_chunks)
+    opt = HipAdamW(model.parameters(), model=model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, amsgrad=False, fused=True)
+    sync = None
+    if world > 1:
+        sync = GradSync(model._flat_grad, model.buckets)
+        model.grad_sync = sync
+    ranges = get_token_type_ranges(lcfg)
+    pad_id = lcfg._base_vocab_size_txt + lcfg.n_dsus + 2 + 4
+
+    n_total = args.warmup + args.steps
+    batches = [{k: v.to(device) for k, v in synthetic_batch(args.batch, args.seq, args.n_dsus, rank=rank, index=i % 4).items()}
+               for i in range(min(n_total, 4))]
+    timer = GemmTimer()
+    if not args.no_gemm_timing and rank == 0:
+        timer.install()
+
+    def one_step(i: int) -> tuple[float, int]:
+        b = batches[i % len(batches)]
+        counts = count_token_types_async(b["tokens"], ranges, pad_id, b["labels"], -100)
+        model.sync_this_backward = True
+        loss_batch = compute_loss(b, model, loss_fn) * counts[-1]
+        loss_batch.backward()
+        host = torch.cat((counts.double(), loss_batch.detach().double().reshape(1))).tolist()  # the step's one D2H sync
+        n_tok, loss_run = int(host[-2]), host[-1]
+        if sync is not None:
+            sync.finish()
+            n_tok, loss_run = (lambda v: (int(round(v[0])), v[1]))(all_reduce_scalars([n_tok, loss_run], device))
+        scale_grads(model, torch.tensor(1.0 / n_tok))
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss_run / n_tok, n_tok
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = float("nan")
+    for i in range(args.warmup):
+        loss, _ = one_step(i)
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = one_step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    tokens_per_step = args.batch * args.seq * world
+    value = tokens_per_step * args.steps / elapsed
+    f_tok = flops_per_token(lcfg.vocab_size, args.seq, layers=args.layers) if args.layers == 16 else None
+    if rank == 0:
+        out = {
+            "metric": "train_tokens_per_sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"Llama-3.2-1B +{args.n_dsus} DSUs (V={lcfg.vocab_size}), SFT step fwd+bwd+AdamW, seq_len={args.seq}, "
+                                   f"batch={args.batch}/GPU, grad_accum=1, {args.layers} layers, random-init weights, MLS-shaped synthetic DSU sequences",
+                       "global_batch": args.batch * world, "seq_len": args.seq, "parallelism": f"dp{world}", "last_loss": loss},
+        }
+        if f_tok:
+            out["mfma_roofline_frac_step"] = value * f_tok / (world * MFMA_PEAK_TFLOPS * 1e12)
+            out["gflop_per_token"] = f_tok / 1e9
+        if timer.records:
+            tot_ms, tot_fl, per = timer.summary()
+            names = {0: "NT", 1: "NN", 2: "TN"}
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "gemm_mfma_kernel<A_COL,B_COL,GLDS> (NT/NN/TN launches of the timed region)",
+                "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+                "launches": len(timer.records), "avg_launch_ms": tot_ms / len(timer.records),
+                "share_of_step_time": tot_ms / (1e3 * elapsed),
+                "per_layout": {names[k]: {"launches": v[0], "avg_ms": v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12} for k, v in per.items()},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(42_831)
+            except Exception as e:  # the GPU number must still be reported
+                out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,129 @@
+/*
+ * ssi_hip.h — C ABI of libssi_hip.so: the MI355X (gfx950) kernels under the speech-integration training hot path.
+ *
+ * The reference (anilkeshwani/speech-integration) reaches its GPU arithmetic only through Python:
+ * ssi/trainer.py -> ssi/loss.py -> torchtune 0.5.0 modules -> ATen.  It has no FFI of its own, so the drop-in boundary
+ * is the Python API (speech-integration_amd/ssi mirrors it); THIS header is the native seam underneath it, one entry per
+ * vendor op the reference hits.  Each entry cites the reference call site it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; the caller (PyTorch's allocator) owns all buffers,
+ *     including workspaces; the library allocates nothing persistent and never synchronises the device.
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered; entries are re-entrant and thread-safe
+ *     (autograd runs backward on another host thread).
+ *   - return 0 on success; SSI_ERR_* otherwise (never throws).  ssi_last_error() gives a thread-local message.
+ *   - dtype: SSI_F32 or SSI_BF16 selects the storage type of activations/weights; reductions, softmax, norms and
+ *     accumulators are always fp32 (the reference's rounding points).
+ *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ */
+#ifndef SSI_HIP_H
+#define SSI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSI_ABI_VERSION 1
+
+enum { SSI_F32 = 0, SSI_BF16 = 1 };
+enum { SSI_OK = 0, SSI_ERR_ARG = 1, SSI_ERR_UNSUPPORTED = 2, SSI_ERR_WORKSPACE = 3, SSI_ERR_HIP = 1000 /* + hipError_t */ };
+/* GEMM operand layouts (row-major storage):
+ *   NT: A[M,K]  B[N,K]   C = A * B^T   forward linear  y = x W^T      (F.linear, torchtune nn.Linear / TiedLinear)
+ *   NN: A[M,K]  B[K,N]   C = A * B     data gradient   dx = dy W
+ *   TN: A[K,M]  B[K,N]   C = A^T * B   weight gradient dW = dy^T x                                                  */
+enum { SSI_GEMM_NT = 0, SSI_GEMM_NN = 1, SSI_GEMM_TN = 2 };
+/* which implementation ssi_gemm may use: AUTO picks the MFMA kernel when shape/dtype allow, else the generic one */
+enum { SSI_IMPL_AUTO = 0, SSI_IMPL_GENERIC = 1, SSI_IMPL_MFMA = 2,
+       SSI_IMPL_MFMA_REGSTAGE = 3 /* debug: MFMA GEMM with register staging instead of LDS-DMA */ };
+
+int ssi_abi_version(void);
+const char* ssi_last_error(void);
+/* force an implementation for kernels that have both a generic and an MFMA path (tests); returns previous value */
+int ssi_set_impl(int impl);
+
+/* ---- K1  nn.Embedding (torchtune TransformerDecoder.tok_embeddings; called from ssi/loss.py:8) ------------------- */
+/* out[t,:] = table[tokens[t],:] */
+int ssi_embed_fwd(const int64_t* tokens, const void* table, void* out, int64_t n_tok, int64_t dim, int64_t vocab,
+                  int dtype, void* stream);
+/* dtable[v,:] += sum_{t: tokens[t]==v} dout[t,:]   (deterministic: sorted segmented sum, fp32 accumulate, no atomics) */
+int64_t ssi_embed_bwd_workspace_bytes(int64_t vocab);
+int ssi_embed_bwd(const int64_t* tokens, const void* dout, void* dtable, int64_t n_tok, int64_t dim, int64_t vocab,
+                  int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- K2  RMSNorm (torchtune.modules.RMSNorm; sa_norm / mlp_norm / norm) ------------------------------------------- */
+/* y = (x32 * rsqrt(mean(x32^2)+eps)).to(dtype) * scale ; rstd[row] saved for backward */
+int ssi_rmsnorm_fwd(const void* x, const void* scale, void* y, float* rstd, int64_t rows, int64_t dim, float eps,
+                    int dtype, void* stream);
+/* dx = d(rmsnorm)/dx . dy (+ dres if non-null);  dscale += sum_rows dy * xhat  (two-stage deterministic reduce).
+ * partials: fp32 workspace of ssi_rmsnorm_bwd_workspace_bytes(rows, dim) bytes. */
+int64_t ssi_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t dim);
+int ssi_rmsnorm_bwd(const void* dy, const void* x, const void* scale, const float* rstd, const void* dres, void* dx,
+                    void* dscale, int64_t rows, int64_t dim, int dtype, void* workspace, int64_t workspace_bytes,
+                    void* stream);
+
+/* ---- K4  Llama3ScaledRoPE (adjacent-pair rotation, fp32 math; torchtune MultiHeadAttention.pos_embeddings) -------- */
+/* x: [rows, ld] rows = b*seq_len + s; rotates heads [0, n_heads_rot) of width head_dim in place; position of a row is
+ * positions[row] if positions != NULL else row % seq_len.  table: [table_len, head_dim/2, 2] fp32 (cos, sin).
+ * inverse != 0 applies the transpose rotation (the backward of the forward rotation). */
+int ssi_rope_inplace(void* x, int64_t ld, int64_t rows, int64_t seq_len, int n_heads_rot, int head_dim,
+                     const float* table, int64_t table_len, const int32_t* positions, int inverse, int dtype,
+                     void* stream);
+
+/* ---- K5  causal GQA attention (F.scaled_dot_product_attention(is_causal=True) inside torchtune MultiHeadAttention) -- */
+/* qkv: [B*S, ld] with q heads at column 0, k heads at n_heads*head_dim, v heads at (n_heads+n_kv)*head_dim.
+ * out: [B*S, n_heads*head_dim].  lse: [B, n_heads, S] fp32 (natural-log sum-exp of scaled scores). */
+int ssi_attn_fwd(const void* qkv, int64_t ld, void* out, float* lse, int64_t batch, int64_t seq, int n_heads,
+                 int n_kv, int head_dim, int dtype, void* stream);
+/* dqkv (same layout as qkv) is fully overwritten. delta: fp32 workspace [B, n_heads, S]. */
+int ssi_attn_bwd(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
+                 float* delta, int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype,
+                 void* stream);
+
+/* ---- K7  SwiGLU elementwise (torchtune FeedForward: w2(silu(w1 x) * w3 x)) ------------------------------------------ */
+/* gu: [rows, 2*inter] = [gate | up]; act[rows, inter] = silu(gate) * up */
+int ssi_swiglu_fwd(const void* gu, void* act, int64_t rows, int64_t inter, int dtype, void* stream);
+int ssi_swiglu_bwd(const void* dact, const void* gu, void* dgu, int64_t rows, int64_t inter, int dtype, void* stream);
+
+/* ---- K3/K6/K7/K8/K10  dense GEMMs (F.linear and its autograd) ------------------------------------------------------- */
+/* C = (accumulate ? C : 0) + alpha * (alpha_dev ? *alpha_dev : 1) * op(A) op(B) + (R ? R : 0)
+ * A, B, C, R share `dtype`; accumulation is fp32.  R (residual) has C's shape and ldc.  The MFMA path needs
+ * dtype == SSI_BF16, M % 256 == 0, N % 256 == 0, K % 64 == 0 and 16-byte aligned rows; otherwise the generic path runs
+ * (or SSI_ERR_UNSUPPORTED if SSI_IMPL_MFMA was forced). */
+int ssi_gemm(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+             void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev, int accumulate, int dtype,
+             void* stream);
+
+/* ---- K9  CEWithChunkedOutputLoss (ssi/trainer.py:300; F.cross_entropy(logits.float(), reduction="sum")) -------------- */
+/* logits: [rows, ld] (columns [0, vocab) are real, [vocab, ld) padding).  labels: already shifted (ssi/loss.py:16).
+ * row_loss[r] = lse(logits[r]) - logits[r, label] (0 if ignored).  If write_grad: logits[r, :] is OVERWRITTEN by
+ * softmax(logits[r]) - onehot(label) (0 for ignored rows and for padding columns) — the unscaled d(sum NLL)/dlogits. */
+int ssi_ce_fwd(void* logits, int64_t ld, const int64_t* labels, int64_t rows, int64_t vocab, int64_t ignore_index,
+               float* row_loss, float* row_lse, int write_grad, int dtype, void* stream);
+/* out[0] = sum(row_loss) / n_valid (NaN if n_valid == 0, as the reference), out[1] = sum(row_loss), out[2] = n_valid */
+int ssi_ce_reduce(const float* row_loss, const int64_t* labels, int64_t rows, int64_t ignore_index, float* out,
+                  void* stream);
+
+/* ---- K14 count_token_types + valid-label count (ssi/train_utils.py:150-165, ssi/trainer.py:388,391) ---------------- */
+/* ranges: n_ranges inclusive [lo, hi] pairs (device int64).  out[0..n_ranges) = per-range counts,
+ * out[n_ranges] = count(tokens != pad_id), out[n_ranges+1] = count(labels != ignore_index).  One launch, no host sync. */
+int ssi_count_tokens(const int64_t* tokens, const int64_t* labels, int64_t n, const int64_t* ranges, int n_ranges,
+                     int64_t pad_id, int64_t ignore_index, int64_t* out, void* stream);
+
+/* ---- K11-K13 scale_grads / clip_grad_norm_ / AdamW (ssi/trainer.py:404-409, ssi/optimizer.py:8-17) ----------------- */
+int ssi_scale_inplace(void* x, int64_t n, float scale, const float* scale_dev, int dtype, void* stream);
+/* out[0] = sum(x^2) in fp32, deterministic two-stage; workspace >= ssi_sumsq_workspace_bytes(n) */
+int64_t ssi_sumsq_workspace_bytes(int64_t n);
+int ssi_sumsq(const void* x, int64_t n, int dtype, float* out, void* workspace, int64_t workspace_bytes, void* stream);
+/* Decoupled-weight-decay Adam on flat buffers, fp32 op-math, one rounding on store (torch fused AdamW semantics):
+ *   g = grad * (grad_scale_dev ? *grad_scale_dev : 1);  p -= lr*wd*p;  m = m + (1-b1)(g-m);  v = b2 v + (1-b2) g g;
+ *   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps),  bc1 = 1-b1^step, bc2 = 1-b2^step.  If zero_grad: grad <- 0. */
+int ssi_adamw_step(void* param, void* grad, void* exp_avg, void* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int64_t step, const float* grad_scale_dev, int zero_grad,
+                   int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSI_HIP_H */

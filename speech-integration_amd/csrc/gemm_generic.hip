@@ -1,0 +1,114 @@
+// Generic GEMM: any shape, fp32 or bf16 storage, fp32 accumulate on the vector ALUs.  This is the fp32 parity path
+// (dtype=fp32 is a supported reference config, /root/reference/ssi/constants.py:25) and the fallback for shapes the
+// MFMA kernel (gemm_mfma.hip) does not take.  64x64 output tile per 256-thread block, 4x4 outputs per thread, BK=16.
+#include "common.cuh"
+
+int ssi_gemm_mfma_bf16(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                       int64_t ldb, void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev,
+                       int accumulate, void* stream);  // gemm_mfma.hip
+bool ssi_gemm_mfma_supported(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                             int64_t ldb, const void* C, int64_t ldc, const void* R);
+
+static int g_impl = SSI_IMPL_AUTO;
+extern "C" int ssi_set_impl(int impl) {
+    const int prev = g_impl;
+    if (impl >= SSI_IMPL_AUTO && impl <= SSI_IMPL_MFMA_REGSTAGE) g_impl = impl;
+    return prev;
+}
+int ssi_get_impl() { return g_impl; }
+
+// element (m,k) of op(A) at A[m*sam + k*sak]; element (k,n) of op(B) at B[k*sbk + n*sbn]
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A,
+                                                           int64_t sam, int64_t sak, const T* __restrict__ B, int64_t sbk,
+                                                           int64_t sbn, T* __restrict__ C, int64_t ldc,
+                                                           const T* __restrict__ R, float alpha,
+                                                           const float* __restrict__ alpha_dev, int accumulate) {
+    constexpr int BM = 64, BN = 64, BK = 16;
+    __shared__ float As[BK][BM + 4];
+    __shared__ float Bs[BK][BN + 4];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    // loader mapping: choose the fast-varying thread index along the contiguous memory dimension
+    const bool a_k_contig = (sak == 1);
+    const bool b_n_contig = (sbn == 1);
+    for (int64_t k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = tid + it * 256;  // 0..1023 over BM x BK
+            int mm, kk;
+            if (a_k_contig) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
+            const int64_t gm = m0 + mm, gk = k0 + kk;
+            As[kk][mm] = (gm < M && gk < K) ? to_f32<T>(A[gm * sam + gk * sak]) : 0.f;
+            int nn, kb;
+            if (b_n_contig) { nn = e & 63; kb = e >> 6; } else { kb = e & 15; nn = e >> 4; }
+            const int64_t gn = n0 + nn, gkb = k0 + kb;
+            Bs[kb][nn] = (gn < N && gkb < K) ? to_f32<T>(B[gkb * sbk + gn * sbn]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    const float al = alpha * (alpha_dev ? *alpha_dev : 1.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t gm = m0 + ty * 4 + i;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t gn = n0 + tx * 4 + j;
+            if (gn >= N) continue;
+            float v = al * acc[i][j];
+            if (accumulate) v += to_f32<T>(C[gm * ldc + gn]);
+            if (R) v += to_f32<T>(R[gm * ldc + gn]);
+            C[gm * ldc + gn] = from_f32<T>(v);
+        }
+    }
+}
+
+extern "C" int ssi_gemm(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                        int64_t ldb, void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev,
+                        int accumulate, int dtype, void* stream) {
+    SSI_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0 && ldc >= N);
+    SSI_CHECK_ARG(layout == SSI_GEMM_NT || layout == SSI_GEMM_NN || layout == SSI_GEMM_TN);
+    if (M == 0 || N == 0) return SSI_OK;
+    int64_t sam, sak, sbk, sbn;
+    if (layout == SSI_GEMM_NT)      { SSI_CHECK_ARG(lda >= K && ldb >= K); sam = lda; sak = 1;   sbk = 1;   sbn = ldb; }
+    else if (layout == SSI_GEMM_NN) { SSI_CHECK_ARG(lda >= K && ldb >= N); sam = lda; sak = 1;   sbk = ldb; sbn = 1; }
+    else                            { SSI_CHECK_ARG(lda >= M && ldb >= N); sam = 1;   sak = lda; sbk = ldb; sbn = 1; }
+
+    const bool mfma_ok = dtype == SSI_BF16 && ssi_gemm_mfma_supported(layout, M, N, K, A, lda, B, ldb, C, ldc, R);
+    if ((g_impl == SSI_IMPL_MFMA || g_impl == SSI_IMPL_MFMA_REGSTAGE) && !mfma_ok) {
+        ssi_set_error("ssi_gemm: MFMA path forced but shape/dtype unsupported (M=%lld N=%lld K=%lld dtype=%d)",
+                      (long long)M, (long long)N, (long long)K, dtype);
+        return SSI_ERR_UNSUPPORTED;
+    }
+    if (mfma_ok && g_impl != SSI_IMPL_GENERIC)
+        return ssi_gemm_mfma_bf16(layout, M, N, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, accumulate, stream);
+
+    SSI_CHECK_ARG(ssi_cdiv(M, 64) <= 65535);
+    dim3 grid((unsigned)ssi_cdiv(N, 64), (unsigned)ssi_cdiv(M, 64));
+    SSI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gemm_generic_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, M, N, K,
+                                                 (const T*)A, sam, sak, (const T*)B, sbk, sbn, (T*)C, ldc, (const T*)R,
+                                                 alpha, alpha_dev, accumulate));
+    SSI_LAUNCH_CHECK();
+    return SSI_OK;
+}

@@ -1,0 +1,257 @@
+// bf16 MFMA GEMM for gfx950 (MI355X): the dense contractions of the training step — QKV / output / gate-up / down
+// projections, the tied LM head, and their data- and weight-gradients.
+//
+// Tile: 256 x 256 x 64 per 512-thread workgroup (8 waves as 2(M) x 4(N), 128 x 64 outputs per wave,
+//       32 accumulator tiles of v_mfma_f32_16x16x32_bf16 = 128 accumulator VGPRs per lane).
+// LDS : 2 buffers x (A 32 KiB + B 32 KiB) = 128 KiB for the K pipeline, reused (144 KiB total) by the epilogue.
+// HBM -> LDS: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip), tile t+1 in flight under the MFMAs of tile t,
+//       one barrier per K-tile.  LDS images are lane-linear; the bank swizzle is applied on the per-lane SOURCE address
+//       and again on the read address (same involution both sides).
+// Operand forms (all three layouts of ssi_gemm use the same main loop):
+//   ROW  tile [rows][64 k]  (k contiguous in memory): fragments by ds_read_b128, 16-B chunk c of row r stored at
+//        chunk c ^ ((r >> 1) & 7)  -> conflict-free for the 16-lane ds_read_b128 groups.
+//   COL  tile [64 k][cols]  (k strided in memory: NN's B, TN's A and B): fragments by 2 x ds_read_b64_tr_b16 (the
+//        hardware transpose read), 16-B chunk c of k-row r stored at chunk c ^ (g(r) << 1),
+//        g(r) = (r & 3) | (((r >> 3) & 1) << 2)  -> the 8 k-rows one half-wave touches land on 8 distinct 32-B slots.
+// Epilogue: accumulators are produced with swapped MFMA operands (D' = B.A^T), so each lane owns 4 consecutive output
+//       columns; they are scaled, rounded to bf16, staged through LDS and written as full 128-B row segments, adding
+//       the residual / previous C in the same pass (same rounding points as F.linear followed by `+`).
+// Workgroup -> tile map: XCD-aware (consecutive tiles of a group share A rows / B columns inside one XCD's L2).
+#include "common.cuh"
+
+int ssi_get_impl();
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int NTHREADS = 512;
+constexpr int WAVES_N = 4;                                   // 2 x 4 wave grid
+constexpr int WM = 128, WN = 64;                             // per-wave output
+constexpr int MT = WM / 16, NT = WN / 16;                    // 8 x 4 accumulator tiles
+constexpr int TILE_BYTES = BM * BK * 2;                      // 32 KiB per operand tile
+constexpr int PIPE_BYTES = 2 * 2 * TILE_BYTES;               // 128 KiB
+constexpr int EPI_ROW_BYTES = WN * 2 + 16;                   // 144 B padded row of a wave's bf16 output tile
+constexpr int EPI_WAVE_BYTES = WM * EPI_ROW_BYTES;           // 18 KiB
+constexpr int LDS_BYTES = 8 * EPI_WAVE_BYTES > PIPE_BYTES ? 8 * EPI_WAVE_BYTES : PIPE_BYTES;  // 144 KiB
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+__device__ __forceinline__ int col_swz(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
+
+// ---- HBM -> LDS staging of one operand tile ------------------------------------------------------------------------
+// ROW: rows r0..r0+255 of a [*, ld] matrix, k columns k0..k0+63.  COL: k-rows k0..k0+63, columns c0..c0+255.
+template <bool COL, bool GLDS>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, int64_t r0, int64_t k0,
+                                           char* lds_tile, int tid, u32x4 (&regs)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const bf16_t* src;
+        if (!COL) {
+            const int row = p * 64 + (tid >> 3);
+            const int chunk = (tid & 7) ^ ((row >> 1) & 7);
+            src = g + (r0 + row) * ld + k0 + chunk * 8;
+        } else {
+            const int krow = p * 16 + (tid >> 5);
+            const int chunk = (tid & 31) ^ col_swz(krow);
+            src = g + (k0 + krow) * ld + r0 + chunk * 8;
+        }
+        if (GLDS) {
+            // wave-uniform LDS base; hardware adds lane*16
+            const int wave_base = __builtin_amdgcn_readfirstlane(p * 8192 + (tid >> 6) * 1024);
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_tile + wave_base), 16, 0, 0);
+        } else {
+            regs[p] = *reinterpret_cast<const u32x4*>(src);
+        }
+    }
+}
+__device__ __forceinline__ void write_staged(char* lds_tile, int tid, const u32x4 (&regs)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(lds_tile + p * 8192 + tid * 16) = regs[p];
+}
+
+// ---- LDS -> MFMA fragment --------------------------------------------------------------------------------------------
+// fragment of 16 "outer" indices (rows of A / columns of B) x 32 k: lane l holds outer = base + (l & 15), k = kh*32 + 8*(l>>4) + j
+template <bool COL>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int outer_base, int kh, int lane) {
+    if (!COL) {
+        const int row = outer_base + (lane & 15);
+        const int chunk = (kh * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
+        return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + chunk * 16);
+    } else {
+        // two transposed reads of 4 k-rows x 16 columns each; in a 16-lane group lane 4q+p addresses k-row q, cols 4p..4p+3
+        const int i = lane & 15, q = i >> 2, p = i & 3;
+        const int kbase = kh * 32 + 8 * (lane >> 4);
+        const int chunk = (outer_base >> 3) + (p >> 1);
+        const int k0 = kbase + q, k1 = kbase + 4 + q;
+        const char* a0 = lds_tile + k0 * 512 + ((chunk ^ col_swz(k0)) * 16) + 8 * (p & 1);
+        const char* a1 = lds_tile + k1 * 512 + ((chunk ^ col_swz(k1)) * 16) + 8 * (p & 1);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, r);
+    }
+}
+
+__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+    // XCD-aware remap (bijective for any grid size): blocks b and b+8 share an XCD, give each XCD a contiguous span
+    const int nwg = tiles_m * tiles_n;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    // grouped order: GM m-tiles x all n-tiles per group
+    constexpr int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int group = t / per_group, in_group = t % per_group;
+    const int gm = (tiles_m - group * GM) < GM ? (tiles_m - group * GM) : GM;
+    tm = group * GM + in_group % gm;
+    tn = in_group / gm;
+}
+
+template <bool A_COL, bool B_COL, bool GLDS>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int tiles_n, int64_t K,
+                                                               const bf16_t* __restrict__ A, int64_t lda,
+                                                               const bf16_t* __restrict__ B, int64_t ldb,
+                                                               bf16_t* __restrict__ C, int64_t ldc,
+                                                               const bf16_t* __restrict__ R, float alpha,
+                                                               const float* __restrict__ alpha_dev, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)(K / BK);
+    u32x4 ra[4], rb[4];
+    auto tileA = [&](int buf) { return smem + buf * 2 * TILE_BYTES; };
+    auto tileB = [&](int buf) { return smem + buf * 2 * TILE_BYTES + TILE_BYTES; };
+
+    stage_tile<A_COL, GLDS>(A, lda, m0, 0, tileA(0), tid, ra);
+    stage_tile<B_COL, GLDS>(B, ldb, n0, 0, tileB(0), tid, rb);
+    if (!GLDS) { write_staged(tileA(0), tid, ra); write_staged(tileB(0), tid, rb); }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();  // tile kt landed (vmcnt(0) + barrier); every wave is done reading buffer cur^1
+        if (kt + 1 < nk) {
+            stage_tile<A_COL, GLDS>(A, lda, m0, (int64_t)(kt + 1) * BK, tileA(cur ^ 1), tid, ra);
+            stage_tile<B_COL, GLDS>(B, ldb, n0, (int64_t)(kt + 1) * BK, tileB(cur ^ 1), tid, rb);
+        }
+        const char* la = tileA(cur);
+        const char* lb = tileB(cur);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            bf16x8 bfr[NT], afr[MT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bfr[j] = read_frag<B_COL>(lb, wn * WN + j * 16, kh, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) afr[i] = read_frag<A_COL>(la, wm * WM + i * 16, kh, lane);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], afr[i], acc[j][i], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (!GLDS && kt + 1 < nk) { write_staged(tileA(cur ^ 1), tid, ra); write_staged(tileB(cur ^ 1), tid, rb); }
+    }
+
+    // ---- epilogue: acc[j][i] holds C[m = wm*128 + i*16 + (lane&15)][n = wn*64 + j*16 + (lane>>4)*4 + r] ----------------
+    __syncthreads();
+    const float al = alpha * (alpha_dev ? *alpha_dev : 1.f);
+    char* ep = smem + wave * EPI_WAVE_BYTES;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[j][i][r] * al);
+            const int row = i * 16 + (lane & 15), col = j * 16 + (lane >> 4) * 4;
+            *reinterpret_cast<bf16x4*>(ep + row * EPI_ROW_BYTES + col * 2) = v;
+        }
+    // each wave reads back only what it wrote: no workgroup barrier needed, the compiler's lgkmcnt wait orders it
+#pragma unroll
+    for (int it = 0; it < WM / 8; ++it) {
+        const int row = it * 8 + (lane >> 3), chunk = lane & 7;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(ep + row * EPI_ROW_BYTES + chunk * 16);
+        const int64_t off = (m0 + wm * WM + row) * ldc + n0 + wn * WN + chunk * 8;
+        if (accumulate || R) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+            if (accumulate) {
+                bf16x8 c = *reinterpret_cast<const bf16x8*>(C + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += (float)c[e];
+            }
+            if (R) {
+                bf16x8 c = *reinterpret_cast<const bf16x8*>(R + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += (float)c[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)f[e];
+        }
+        *reinterpret_cast<bf16x8*>(C + off) = v;
+    }
+}
+
+template <bool A_COL, bool B_COL, bool GLDS>
+int launch(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+           int64_t ldc, const void* R, float alpha, const float* alpha_dev, int accumulate, hipStream_t st) {
+    auto kern = gemm_mfma_kernel<A_COL, B_COL, GLDS>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) { ssi_set_error("gemm_mfma: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return SSI_ERR_HIP + (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(NTHREADS), LDS_BYTES, st, tiles_m, tiles_n, K,
+                       (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (const bf16_t*)R, alpha, alpha_dev,
+                       accumulate);
+    SSI_LAUNCH_CHECK();
+    return SSI_OK;
+}
+
+bool use_glds() { return ssi_get_impl() != SSI_IMPL_MFMA_REGSTAGE; }  // default: LDS-DMA staging
+
+}  // namespace
+
+bool ssi_gemm_mfma_supported(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                             int64_t ldb, const void* C, int64_t ldc, const void* R) {
+    if (M <= 0 || N <= 0 || K <= 0) return false;
+    if (M % BM || N % BN || K % BK) return false;
+    if (lda % 8 || ldb % 8 || ldc % 8) return false;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)R) & 15) return false;
+    if ((M / BM) * (N / BN) > (1LL << 30)) return false;
+    (void)layout;
+    return true;
+}
+
+int ssi_gemm_mfma_bf16(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                       int64_t ldb, void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev,
+                       int accumulate, void* stream) {
+    const int tm = (int)(M / BM), tn = (int)(N / BN);
+    auto st = (hipStream_t)stream;
+    const bool g = use_glds();
+#define GO(AC, BC)                                                                                                     \
+    return g ? launch<AC, BC, true>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, accumulate, st)            \
+             : launch<AC, BC, false>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, accumulate, st)
+    switch (layout) {
+        case SSI_GEMM_NT: GO(false, false);
+        case SSI_GEMM_NN: GO(false, true);
+        case SSI_GEMM_TN: GO(true, true);
+    }
+#undef GO
+    return SSI_ERR_ARG;
+}

@@ -1,0 +1,106 @@
+"""ctypes binding of ``libssi_hip.so`` (C ABI declared in ``include/ssi_hip.h``).
+
+The product path has NO CPU fallback: if the shared library is missing or a GPU entry is called on a non-GPU tensor,
+this module raises.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C speech-integration_amd/csrc``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libssi_hip.so")
+
+SSI_F32, SSI_BF16 = 0, 1
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_MFMA_REGSTAGE = 0, 1, 2, 3
+ABI_VERSION = 1
+
+# name -> (restype, argtypes); mirrors include/ssi_hip.h line by line
+_P = c_void_p
+PROTOTYPES = {
+    "ssi_abi_version": (c_int, []),
+    "ssi_last_error": (c_char_p, []),
+    "ssi_set_impl": (c_int, [c_int]),
+    "ssi_embed_fwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, _P]),
+    "ssi_embed_bwd_workspace_bytes": (c_int64, [c_int64]),
+    "ssi_embed_bwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, _P, c_int64, _P]),
+    "ssi_rmsnorm_fwd": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_float, c_int, _P]),
+    "ssi_rmsnorm_bwd_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "ssi_rmsnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P]),
+    "ssi_rope_inplace": (c_int, [_P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, _P, c_int, c_int, _P]),
+    "ssi_attn_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_int, _P]),
+    "ssi_attn_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_int, _P]),
+    "ssi_swiglu_fwd": (c_int, [_P, _P, c_int64, c_int64, c_int, _P]),
+    "ssi_swiglu_bwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P]),
+    "ssi_gemm": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_float, _P,
+                         c_int, c_int, _P]),
+    "ssi_ce_fwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, c_int, c_int, _P]),
+    "ssi_ce_reduce": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
+    "ssi_count_tokens": (c_int, [_P, _P, c_int64, _P, c_int, c_int64, c_int64, _P, _P]),
+    "ssi_scale_inplace": (c_int, [_P, c_int64, c_float, _P, c_int, _P]),
+    "ssi_sumsq_workspace_bytes": (c_int64, [c_int64]),
+    "ssi_sumsq": (c_int, [_P, c_int64, c_int, _P, _P, c_int64, _P]),
+    "ssi_adamw_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, _P, c_int,
+                               c_int, _P]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the shared library.  Raises ``HipLibraryError`` if it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). Build it with "
+            f"`make -C {os.path.join(os.path.dirname(_HERE), 'csrc')}` or `__graft_entry__.build()`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    v = lib.ssi_abi_version()
+    if v != ABI_VERSION:
+        raise HipLibraryError(f"libssi_hip ABI version {v} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ssi_last_error()
+        raise RuntimeError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return SSI_F32
+    if dtype == torch.bfloat16:
+        return SSI_BF16
+    raise TypeError(f"unsupported dtype {dtype}; supported: torch.float32, torch.bfloat16")
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipLibraryError("libssi_hip kernels need GPU tensors (there is no CPU fallback in the product path)")
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream

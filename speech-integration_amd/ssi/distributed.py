@@ -1,0 +1,129 @@
+"""Data-parallel gradient exchange over RCCL/xGMI (one process per GPU).
+
+The reference has no gradient synchronisation at all (``DistributedSampler`` + ``world_size`` bookkeeping
+only, ``/root/reference/ssi/trainer.py:519``).  This module supplies it MI355X-first: the model's gradients already live in
+one flat HBM buffer, so the exchange is a handful of large in-place SUM all-reduces over contiguous per-layer buckets
+(~122 MB bf16 each at the 1B shape; the tied embedding bucket, 546 MB, last), each issued on a side stream as soon as
+backward has finished that bucket and overlapped with the rest of backward.  ``torch.distributed`` backend ``nccl`` is
+RCCL on ROCm; ``gloo`` is used by the CPU tests.  After the exchange every rank scales by 1 / (sum over ranks of
+``num_tokens_step``), which makes an N-GPU step equal to the reference's single-process step with N x as many
+micro-batches.
+"""
+
+from __future__ import annotations
+
+import datetime
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def get_world_size_and_rank() -> tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+
+
+def init_distributed(device: torch.device, timeout_s: int = 600) -> tuple[int, int]:
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun).  No-op for single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 1, 0
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "nccl" if device.type == "cuda" else "gloo"
+        kwargs = {}
+        if device.type == "cuda":
+            torch.cuda.set_device(device)
+            kwargs["device_id"] = device
+        dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+    return dist.get_world_size(), dist.get_rank()
+
+
+class GradSync:
+    """Bucketed in-place SUM all-reduce of a flat gradient buffer.
+
+    ``bucket_ready(name, lo, hi)`` is called by the model's backward as soon as ``flat_grad[lo:hi]`` is final;
+    ``finish()`` reduces whatever was not announced and blocks the compute stream on all outstanding reductions."""
+
+    def __init__(self, flat_grad: Tensor, buckets: list[tuple[str, int, int]], group=None):
+        self.flat_grad, self.buckets, self.group = flat_grad, list(buckets), group
+        self._pending: list = []
+        self._done: set[str] = set()
+        self._comm_stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
+        self.bytes_reduced = 0
+
+    @property
+    def enabled(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def bucket_ready(self, name: str, lo: int, hi: int) -> None:
+        if not self.enabled or name in self._done or hi <= lo:
+            return
+        self._done.add(name)
+        buf = self.flat_grad[lo:hi]
+        self.bytes_reduced += buf.numel() * buf.element_size()
+        if self._comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(buf.device))
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ev)
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append(work)
+
+    def finish(self) -> None:
+        if self.enabled:
+            for name, lo, hi in self.buckets:
+                self.bucket_ready(name, lo, hi)
+            for work in self._pending:
+                work.wait()
+            if self._comm_stream is not None:
+                torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._comm_stream)
+        self._pending.clear()
+        self._done.clear()
+
+    @classmethod
+    def for_module(cls, module: torch.nn.Module, group=None) -> "ModuleGradSync":
+        return ModuleGradSync(module, group)
+
+
+class ModuleGradSync(GradSync):
+    """Gradient exchange for a foreign ``nn.Module`` (stand-in models in host tests): gradients are gathered into one
+    buffer at ``finish()``, reduced with a single collective and scattered back.  The HIP decoder never takes this route
+    (its gradients are born flat and are reduced bucket by bucket during backward)."""
+
+    def __init__(self, module: torch.nn.Module, group=None):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        super().__init__(torch.empty(0, device=dev), [], group)
+
+    def bucket_ready(self, name: str, lo: int, hi: int) -> None:  # no early buckets for foreign modules
+        return
+
+    def finish(self) -> None:
+        if not self.enabled:
+            return
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.bytes_reduced += flat.numel() * flat.element_size()
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+
+def all_reduce_scalars(values: list[float], device: torch.device, group=None) -> list[float]:
+    """SUM-reduce a few host scalars across ranks (token counts, running loss) in one tiny collective."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return list(values)
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.tolist()

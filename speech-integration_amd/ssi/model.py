@@ -1,0 +1,561 @@
+"""Llama-3.2 decoder with a DSU-extended, tied vocabulary on hand-written HIP kernels (gfx950).
+
+Replaces what the reference builds at ``/root/reference/ssi/model.py:18-39`` (torchtune ``llama3_2(**params)``) and runs at
+``/root/reference/ssi/loss.py:8-14``.  Public surface kept: ``setup_llama3_2_1b(cfg, llama_config, model_state_dict,
+dtype_default, device_default)``; the returned module is callable as ``model(tokens=, mask=, encoder_input=,
+encoder_mask=, input_pos=)``, has ``set_num_output_chunks``, exposes torchtune-format ``state_dict`` keys
+ and populates ``p.grad`` on ``loss.backward()``.
+
+MI355X-first design (not a module-per-op port):
+* all parameters live in ONE flat HBM buffer (q/k/v fused to one [3072, D] weight, gate/up fused to one [2I, D] weight;
+  the torchtune-named parameters are row-slice views), gradients and AdamW moments in matching flat buffers, so the
+  optimizer is a single streaming kernel and data-parallel all-reduce works on contiguous per-layer buckets;
+* the embedding table is stored with its row count padded to a multiple of 256 so that the LM-head GEMM, its dgrad and
+  its wgrad run on full MFMA tiles (pad rows are zero and stay zero);
+* forward/backward are two hand-scheduled kernel sequences over a persistent activation arena (stable pointers, no
+  allocator traffic, no autograd graph of small ops) wrapped in three ``torch.autograd.Function`` seams:
+  decoder stack, tied head -> logits, tied head + cross-entropy (logits are written once in the model dtype and turned
+  into their gradient in place);
+* there is no CPU path: constructing the model off-GPU raises.
+"""
+
+from __future__ import annotations
+
+import logging
+import math
+from typing import Any, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib, ops
+from .constants import CROSS_ENTROPY_IGNORE_IDX, PRECISION_STR_TO_DTYPE
+from .llama_configs import ConfigLlama3_2
+from .ops import GEMM_NN, GEMM_NT, GEMM_TN
+
+LOGGER = logging.getLogger(__name__)
+
+VOCAB_ALIGN = 256  # MFMA tile edge
+
+
+def _align(n: int, a: int) -> int:
+    return (n + a - 1) // a * a
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# RoPE table (torchtune Llama3ScaledRoPE: rope_init / apply_scaling / build_rope_cache).
+# Host-side fp32 tensor arithmetic, done once; the rotation itself is the HIP kernel ``ssi_rope_inplace``.
+# --------------------------------------------------------------------------------------------------------------------
+def llama3_rope_table(head_dim: int, max_seq_len: int, base: float = 500_000, scale_factor: float = 32,
+                      low_freq_factor: float = 1, high_freq_factor: float = 4, old_context_len: int = 8192) -> Tensor:
+    freqs = 1.0 / (base ** (torch.arange(0, head_dim, 2)[: head_dim // 2].float() / head_dim))
+    lo_wl, hi_wl = old_context_len / low_freq_factor, old_context_len / high_freq_factor
+    out = []
+    for f in freqs:
+        wavelen = 2 * math.pi / f
+        if wavelen < hi_wl:
+            out.append(f)
+        elif wavelen > lo_wl:
+            out.append(f / scale_factor)
+        else:
+            smooth = (old_context_len / wavelen - low_freq_factor) / (high_freq_factor - low_freq_factor)
+            out.append((1 - smooth) * f / scale_factor + smooth * f)
+    theta = torch.stack([t.to(torch.float32) for t in out])
+    idx = torch.einsum("i, j -> ij", torch.arange(max_seq_len, dtype=theta.dtype), theta).float()
+    return torch.stack([torch.cos(idx), torch.sin(idx)], dim=-1).contiguous()  # [max_seq_len, head_dim/2, 2]
+
+
+class _Holder(nn.Module):
+    """Parameter container so that ``state_dict`` / ``named_parameters`` carry torchtune's dotted names."""
+
+
+class _Arena:
+    """Persistent activation / workspace buffers keyed by name (stable device pointers across steps)."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.buf: dict[str, Tensor] = {}
+
+    def get(self, name: str, shape: tuple, dtype: torch.dtype) -> Tensor:
+        n = 1
+        for s in shape:
+            n *= s
+        t = self.buf.get(name)
+        if t is None or t.dtype != dtype or t.numel() < n:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self.buf[name] = t
+        return t[:n].view(shape)
+
+    def bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.buf.values())
+
+
+class HipLlamaDecoder(nn.Module):
+    def __init__(self, vocab_size: int, num_layers: int, num_heads: int, num_kv_heads: int, embed_dim: int,
+                 max_seq_len: int, intermediate_dim: int, attn_dropout: float = 0.0, norm_eps: float = 1e-5,
+                 rope_base: int = 500_000, scale_factor: int = 32, *, dtype: torch.dtype = torch.bfloat16,
+                 device: torch.device | str = "cuda", rope_cache_len: Optional[int] = None) -> None:
+        super().__init__()
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        if device.type != "cuda":
+            raise _lib.HipLibraryError(
+                f"HipLlamaDecoder runs only on an MI355X GPU through libssi_hip.so (got device={device}); "
+                "there is no CPU fallback in the product path")
+        _lib.load()
+        if attn_dropout != 0.0:
+            raise NotImplementedError("attn_dropout must be 0.0 (the reference config, llama_configs.py:136)")
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f"unsupported dtype {dtype}")
+        if embed_dim % num_heads or num_heads % num_kv_heads or embed_dim % 8 or intermediate_dim % 8:
+            raise ValueError("embed_dim must divide into heads, heads into kv heads, and dims must be multiples of 8")
+        self.vocab_size, self.num_layers = vocab_size, num_layers
+        self.num_heads, self.num_kv_heads = num_heads, num_kv_heads
+        self.embed_dim, self.intermediate_dim = embed_dim, intermediate_dim
+        self.head_dim = embed_dim // num_heads
+        self.max_seq_len, self.norm_eps = max_seq_len, float(norm_eps)
+        self.dtype, self.device = dtype, device
+        self.vocab_pad = _align(vocab_size, VOCAB_ALIGN)
+        self.qkv_dim = (num_heads + 2 * num_kv_heads) * self.head_dim
+        self.num_output_chunks = 0
+        self.ignore_index = CROSS_ENTROPY_IGNORE_IDX
+
+        D, I, Q, KVD = embed_dim, intermediate_dim, num_heads * self.head_dim, num_kv_heads * self.head_dim
+        # ---- flat parameter layout ------------------------------------------------------------------------------
+        off = 0
+        self._slices: dict[str, tuple[int, tuple]] = {}
+
+        def take(name: str, shape: tuple) -> None:
+            nonlocal off
+            n = 1
+            for s in shape:
+                n *= s
+            self._slices[name] = (off, shape)
+            off += _align(n, 8)
+
+        take("emb", (self.vocab_pad, D))
+        for l in range(num_layers):
+            take(f"L{l}.wqkv", (self.qkv_dim, D))
+            take(f"L{l}.wo", (D, Q))
+            take(f"L{l}.w13", (2 * I, D))
+            take(f"L{l}.w2", (D, I))
+            take(f"L{l}.sa_norm", (D,))
+            take(f"L{l}.mlp_norm", (D,))
+        take("norm", (D,))
+        self._flat_numel = off
+        self._flat = torch.zeros(off, dtype=dtype, device=device)
+        self._flat_grad = torch.zeros(off, dtype=dtype, device=device)
+        self._grad_views: dict[str, Tensor] = {}
+        # DP buckets in the order backward finishes them: final norm, layers L-1..0, embedding (tied: finished last)
+        self.buckets: list[tuple[str, int, int]] = []
+        lo, _ = self._slices["norm"]
+        self.buckets.append(("norm", lo, off))
+        for l in reversed(range(num_layers)):
+            lo = self._slices[f"L{l}.wqkv"][0]
+            hi = self._slices[f"L{l + 1}.wqkv"][0] if l + 1 < num_layers else self._slices["norm"][0]
+            self.buckets.append((f"L{l}", lo, hi))
+        self.buckets.append(("emb", 0, self._slices["L0.wqkv"][0] if num_layers else self._slices["norm"][0]))
+
+        # ---- torchtune-named parameters as views ------------------------------------------------------------------
+        def view(name: str, rows: Optional[tuple[int, int]] = None, buf: Optional[Tensor] = None) -> Tensor:
+            o, shape = self._slices[name]
+            n = 1
+            for s in shape:
+                n *= s
+            t = (self._flat if buf is None else buf)[o:o + n].view(shape)
+            return t if rows is None else t[rows[0]:rows[1]]
+
+        self._view = view
+        self._param_src: list[tuple[nn.Parameter, str, Optional[tuple[int, int]]]] = []
+
+        def param(holder: nn.Module, attr: str, name: str, rows: Optional[tuple[int, int]] = None) -> None:
+            p = nn.Parameter(view(name, rows))
+            setattr(holder, attr, p)
+            self._param_src.append((p, name, rows))
+
+        self.tok_embeddings = _Holder()
+        param(self.tok_embeddings, "weight", "emb", (0, vocab_size))
+        self.layers = nn.ModuleList()
+        for l in range(num_layers):
+            layer = _Holder()
+            layer.attn = _Holder()
+            for nm, rows in (("q_proj", (0, Q)), ("k_proj", (Q, Q + KVD)), ("v_proj", (Q + KVD, Q + 2 * KVD))):
+                h = _Holder()
+                param(h, "weight", f"L{l}.wqkv", rows)
+                setattr(layer.attn, nm, h)
+            h = _Holder()
+            param(h, "weight", f"L{l}.wo")
+            layer.attn.output_proj = h
+            layer.mlp = _Holder()
+            for nm, src, rows in (("w1", "w13", (0, I)), ("w2", "w2", None), ("w3", "w13", (I, 2 * I))):
+                h = _Holder()
+                param(h, "weight", f"L{l}.{src}", rows)
+                setattr(layer.mlp, nm, h)
+            layer.sa_norm = _Holder()
+            param(layer.sa_norm, "scale", f"L{l}.sa_norm")
+            layer.mlp_norm = _Holder()
+            param(layer.mlp_norm, "scale", f"L{l}.mlp_norm")
+            self.layers.append(layer)
+        self.norm = _Holder()
+        param(self.norm, "scale", "norm")
+        with torch.no_grad():
+            for p, name, _ in self._param_src:
+                if name.endswith("norm"):
+                    p.fill_(1.0)
+
+        cache_len = min(rope_cache_len or max_seq_len, max_seq_len)
+        self._rope = llama3_rope_table(self.head_dim, cache_len, rope_base, scale_factor).to(device)
+        self._arena = _Arena(device)
+        self._anchor = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)
+        self._saved: Optional[dict] = None       # activations of the forward awaiting its backward
+        self._fwd_generation = 0
+        self.pending_grad_scale: Optional[Tensor] = None  # lazy scale_grads (device fp32 scalar), consumed by the optimizer
+        self._grads_dirty = False
+        self.grad_sync = None                             # optional ssi.distributed.GradSync
+        self.sync_this_backward = False
+
+    # ---- nn.Module plumbing ------------------------------------------------------------------------------------------
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.empty(0, dtype=self.dtype, device=self.device))
+        if probe.device != self.device or probe.dtype != self.dtype:
+            raise NotImplementedError("HipLlamaDecoder is created on its target device/dtype; .to() cannot move it")
+        return self
+
+    def set_num_output_chunks(self, num_output_chunks: int) -> None:
+        """Kept for API parity (``trainer.py:304``).  The fused loss path never materialises per-chunk logits lists;
+        ``forward`` still returns ``num_output_chunks`` sequence chunks when asked for logits."""
+        self.num_output_chunks = int(num_output_chunks)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        own = dict(self.named_parameters())
+        missing = [k for k in own if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in own]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing keys {missing}, unexpected keys {unexpected}")
+        with torch.no_grad():
+            for k, p in own.items():
+                if k in state_dict:
+                    src = state_dict[k]
+                    if tuple(src.shape) != tuple(p.shape):
+                        raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(src.shape)} vs model {tuple(p.shape)}")
+                    p.copy_(src.to(device=self.device, dtype=self.dtype))
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def attach_grads(self) -> None:
+        """Point every ``p.grad`` at its slice of the flat gradient buffer (idempotent)."""
+        for p, name, rows in self._param_src:
+            if p.grad is None:
+                p.grad = self._view(name, rows, self._flat_grad)
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        if self._grads_dirty:  # the fused optimizer step already zeroes the buffer in its own pass
+            self._flat_grad.zero_()
+            self._grads_dirty = False
+        self.pending_grad_scale = None
+        if set_to_none:
+            for p, _, _ in self._param_src:
+                p.grad = None
+
+    def activation_bytes(self) -> int:
+        return self._arena.bytes()
+
+    # ---- batch geometry ----------------------------------------------------------------------------------------------
+    def _mfma_shapes(self) -> bool:
+        D, I = self.embed_dim, self.intermediate_dim
+        return (self.dtype == torch.bfloat16 and D % 256 == 0 and self.qkv_dim % 256 == 0 and (2 * I) % 256 == 0
+                and I % 64 == 0 and (self.num_heads * self.head_dim) % 64 == 0)
+
+    def padded_seq_len(self, batch: int, seq: int) -> int:
+        """Sequence length after right-padding so that batch*seq fills whole 256-row MFMA tiles.  Right padding is the
+        reference's own batch format (pad_id / -100, ``ssi/data/__init__.py:174-199``): causal attention and the ignored
+        labels make it numerically inert for the real positions."""
+        if not self._mfma_shapes():
+            return seq
+        g = 256 // math.gcd(batch, 256)
+        g = max(g, 64)
+        return _align(seq, g)
+
+    # ---- forward: decoder stack --------------------------------------------------------------------------------------
+    def _forward_hidden(self, tokens: Tensor, save: bool) -> Tensor:
+        B, S = tokens.shape
+        T, D, I = B * S, self.embed_dim, self.intermediate_dim
+        H, KV, hd, dt, A = self.num_heads, self.num_kv_heads, self.head_dim, self.dtype, self._arena
+        if S > self._rope.shape[0]:
+            raise ValueError(f"sequence length {S} exceeds the RoPE cache ({self._rope.shape[0]})")
+        tok = tokens.reshape(-1).contiguous()
+        L = self.num_layers
+        h = A.get("h0", (T, D), dt)
+        ops.embed_fwd(tok, self._view("emb"), h, self.vocab_size)
+        for l in range(L):
+            sfx = f"{l}" if save else "x"
+            xn1 = A.get(f"xn1.{sfx}", (T, D), dt)
+            rstd1 = A.get(f"rstd1.{sfx}", (T,), torch.float32)
+            ops.rmsnorm_fwd(h, self._view(f"L{l}.sa_norm"), xn1, rstd1, self.norm_eps)
+            qkv = A.get(f"qkv.{sfx}", (T, self.qkv_dim), dt)
+            ops.gemm(GEMM_NT, xn1, self._view(f"L{l}.wqkv"), qkv)
+            ops.rope_(qkv, S, H + KV, hd, self._rope)
+            att = A.get(f"att.{sfx}", (T, H * hd), dt)
+            lse = A.get(f"lse.{sfx}", (B * H * S,), torch.float32)
+            ops.attn_fwd(qkv, att, lse, B, S, H, KV, hd)
+            hmid = A.get(f"hmid.{sfx}", (T, D), dt)
+            ops.gemm(GEMM_NT, att, self._view(f"L{l}.wo"), hmid, residual=h)
+            xn2 = A.get(f"xn2.{sfx}", (T, D), dt)
+            rstd2 = A.get(f"rstd2.{sfx}", (T,), torch.float32)
+            ops.rmsnorm_fwd(hmid, self._view(f"L{l}.mlp_norm"), xn2, rstd2, self.norm_eps)
+            gu = A.get(f"gu.{sfx}", (T, 2 * I), dt)
+            ops.gemm(GEMM_NT, xn2, self._view(f"L{l}.w13"), gu)
+            act = A.get(f"act.{sfx}", (T, I), dt)
+            ops.swiglu_fwd(gu, act)
+            hn_name = f"h{l + 1}" if save else f"hx{l & 1}"
+            hnext = A.get(hn_name, (T, D), dt)
+            ops.gemm(GEMM_NT, act, self._view(f"L{l}.w2"), hnext, residual=hmid)
+            h = hnext
+        hn = A.get("hn", (T, D), dt)
+        rstdf = A.get("rstdf", (T,), torch.float32)
+        ops.rmsnorm_fwd(h, self.norm.scale, hn, rstdf, self.norm_eps)
+        if save:
+            self._fwd_generation += 1
+            self._saved = {"tok": tok, "B": B, "S": S, "gen": self._fwd_generation}
+        return hn
+
+    # ---- backward: decoder stack -------------------------------------------------------------------------------------
+    def _backward_hidden(self, d_hn: Tensor, gen: int) -> None:
+        sv = self._saved
+        if sv is None or sv["gen"] != gen:
+            raise RuntimeError("HipLlamaDecoder: backward called for a forward whose activations were overwritten; "
+                               "run backward before the next training forward")
+        B, S, tok = sv["B"], sv["S"], sv["tok"]
+        T, D, I = B * S, self.embed_dim, self.intermediate_dim
+        H, KV, hd, dt, A = self.num_heads, self.num_kv_heads, self.head_dim, self.dtype, self._arena
+        L = self.num_layers
+        G = self._flat_grad
+        self._grads_dirty = True
+        gv = lambda name: self._view(name, None, G)  # noqa: E731
+        ws = A.get("ws.rms", (max(ops.rmsnorm_bwd_workspace_bytes(T, D), 16),), torch.uint8)
+        sync = self.grad_sync if (self.grad_sync is not None and self.sync_this_backward) else None
+
+        dh = A.get("dh.a", (T, D), dt)
+        ops.rmsnorm_bwd(d_hn, A.get(f"h{L}", (T, D), dt), self.norm.scale, A.get("rstdf", (T,), torch.float32), None, dh,
+                        gv("norm"), ws)
+        if sync:
+            sync.bucket_ready(*self.buckets[0])
+        for l in reversed(range(L)):
+            xn1, xn2 = A.get(f"xn1.{l}", (T, D), dt), A.get(f"xn2.{l}", (T, D), dt)
+            qkv, att = A.get(f"qkv.{l}", (T, self.qkv_dim), dt), A.get(f"att.{l}", (T, H * hd), dt)
+            hmid, gu, act = A.get(f"hmid.{l}", (T, D), dt), A.get(f"gu.{l}", (T, 2 * I), dt), A.get(f"act.{l}", (T, I), dt)
+            h_in = A.get(f"h{l}", (T, D), dt)
+            # MLP: h_out = hmid + act @ w2^T
+            dact = A.get("dact", (T, I), dt)
+            ops.gemm(GEMM_NN, dh, self._view(f"L{l}.w2"), dact)
+            ops.gemm(GEMM_TN, dh, act, gv(f"L{l}.w2"), accumulate=True)
+            dgu = A.get("dgu", (T, 2 * I), dt)
+            ops.swiglu_bwd(dact, gu, dgu)
+            dxn = A.get("dxn", (T, D), dt)
+            ops.gemm(GEMM_NN, dgu, self._view(f"L{l}.w13"), dxn)
+            ops.gemm(GEMM_TN, dgu, xn2, gv(f"L{l}.w13"), accumulate=True)
+            dhmid = A.get("dh.b", (T, D), dt)
+            ops.rmsnorm_bwd(dxn, hmid, self._view(f"L{l}.mlp_norm"), A.get(f"rstd2.{l}", (T,), torch.float32), dh, dhmid,
+                            gv(f"L{l}.mlp_norm"), ws)
+            # attention: hmid = h_in + att @ wo^T
+            datt = A.get("datt", (T, H * hd), dt)
+            ops.gemm(GEMM_NN, dhmid, self._view(f"L{l}.wo"), datt)
+            ops.gemm(GEMM_TN, dhmid, att, gv(f"L{l}.wo"), accumulate=True)
+            dqkv = A.get("dqkv", (T, self.qkv_dim), dt)
+            delta = A.get("delta", (B * H * S,), torch.float32)
+            ops.attn_bwd(qkv, att, datt, A.get(f"lse.{l}", (B * H * S,), torch.float32), dqkv, delta, B, S, H, KV, hd)
+            ops.rope_(dqkv, S, H + KV, hd, self._rope, inverse=True)
+            ops.gemm(GEMM_NN, dqkv, self._view(f"L{l}.wqkv"), dxn)
+            ops.gemm(GEMM_TN, dqkv, xn1, gv(f"L{l}.wqkv"), accumulate=True)
+            ops.rmsnorm_bwd(dxn, h_in, self._view(f"L{l}.sa_norm"), A.get(f"rstd1.{l}", (T,), torch.float32), dhmid, dh,
+                            gv(f"L{l}.sa_norm"), ws)
+            if sync:
+                sync.bucket_ready(*self.buckets[1 + (L - 1 - l)])
+        ws_e = A.get("ws.emb", (max(_lib.load().ssi_embed_bwd_workspace_bytes(self.vocab_size), 16),), torch.uint8)
+        ops.embed_bwd(tok, dh, gv("emb"), self.vocab_size, ws_e)
+        if sync:
+            sync.bucket_ready(*self.buckets[-1])
+        self._saved = None
+        self.attach_grads()
+
+    # ---- tied LM head ------------------------------------------------------------------------------------------------
+    def _head_logits(self, hn: Tensor) -> Tensor:
+        T = hn.shape[0]
+        logits = self._arena.get("logits", (T, self.vocab_pad), self.dtype)
+        ops.gemm(GEMM_NT, hn, self._view("emb"), logits)
+        return logits
+
+    def _head_backward(self, dlogits: Tensor, hn: Tensor, alpha_dev: Optional[Tensor]) -> Tensor:
+        """d_hn = alpha * dlogits @ E ;  dE += alpha * dlogits^T @ hn   (dlogits: [T, vocab_pad], pad columns zero)."""
+        T, D = hn.shape
+        self._grads_dirty = True
+        d_hn = self._arena.get("d_hn", (T, D), self.dtype)
+        ops.gemm(GEMM_NN, dlogits, self._view("emb"), d_hn, alpha_dev=alpha_dev)
+        ops.gemm(GEMM_TN, dlogits, hn, self._view("emb", None, self._flat_grad), alpha_dev=alpha_dev, accumulate=True)
+        return d_hn
+
+    # ---- public API --------------------------------------------------------------------------------------------------
+    def _check_inputs(self, tokens: Tensor, mask, encoder_input, encoder_mask, input_pos) -> Tensor:
+        if mask is not None or encoder_input is not None or encoder_mask is not None or input_pos is not None:
+            raise NotImplementedError("only tokens= is supported: the reference's collate emits no mask/input_pos "
+                                      "(ssi/data/__init__.py:199) and has no encoder inputs")
+        if tokens.dim() != 2 or tokens.dtype != torch.int64:
+            raise ValueError("tokens must be an int64 tensor of shape [batch, seq]")
+        if not tokens.is_cuda:
+            raise _lib.HipLibraryError("tokens must live on the GPU (no CPU fallback)")
+        return tokens
+
+    def forward_hidden(self, tokens: Tensor) -> Tensor:
+        """Final-normed hidden states [B, S, D] (autograd-aware)."""
+        B, S = tokens.shape
+        if torch.is_grad_enabled() and self.training:
+            hn = _DecoderFn.apply(self, tokens, self._anchor)
+        else:
+            hn = self._forward_hidden(tokens, save=False)
+        return hn.view(B, S, self.embed_dim)
+
+    def forward(self, tokens: Tensor, mask=None, encoder_input=None, encoder_mask=None, input_pos=None):
+        """Logits.  ``num_output_chunks > 0``: list of [B, ceil(S/n), V] chunks in the model dtype (torch.chunk rule,
+        SURVEY.md Appendix A.4); else one fp32 [B, S, V] tensor — as torchtune's ``TransformerDecoder.forward``."""
+        tokens = self._check_inputs(tokens, mask, encoder_input, encoder_mask, input_pos)
+        B, S = tokens.shape
+        hn = self.forward_hidden(tokens).view(B * S, self.embed_dim)
+        if torch.is_grad_enabled() and self.training:
+            logits = _HeadLogitsFn.apply(self, hn, self._anchor)
+        else:
+            logits = self._head_logits(hn)
+        logits = logits.view(B, S, self.vocab_pad)[..., : self.vocab_size]
+        if self.num_output_chunks > 0:
+            return list(logits.chunk(self.num_output_chunks, dim=1))
+        return logits.float()
+
+    def fused_loss(self, tokens: Tensor, shifted_labels: Tensor, ignore_index: int = CROSS_ENTROPY_IGNORE_IDX) -> Tensor:
+        """Mean NLL over non-ignored (already shifted) labels with the LM head + CE fused: equals
+        ``CEWithChunkedOutputLoss()(model(tokens), shifted_labels)`` of the reference for any chunk count."""
+        tokens = self._check_inputs(tokens, None, None, None, None)
+        B, S = tokens.shape
+        Sp = self.padded_seq_len(B, S)
+        if Sp != S:
+            pad_t = torch.zeros(B, Sp - S, dtype=tokens.dtype, device=tokens.device)
+            tokens = torch.cat([tokens, pad_t], dim=1)
+            shifted_labels = torch.cat([shifted_labels, torch.full_like(pad_t, ignore_index)], dim=1)
+        labels = shifted_labels.reshape(-1).contiguous()
+        if torch.is_grad_enabled() and self.training:
+            return _FusedLossFn.apply(self, tokens, labels, ignore_index, self._anchor)
+        hn = self._forward_hidden(tokens, save=False)
+        return self._ce_forward(hn, labels, ignore_index, write_grad=False)[0]
+
+    def _ce_forward(self, hn: Tensor, labels: Tensor, ignore_index: int, write_grad: bool) -> tuple[Tensor, Tensor, Tensor]:
+        T = hn.shape[0]
+        logits = self._head_logits(hn)
+        row_loss = self._arena.get("row_loss", (T,), torch.float32)
+        ops.ce_fwd(logits, labels, self.vocab_size, ignore_index, row_loss, None, write_grad)
+        out = torch.empty(3, dtype=torch.float32, device=self.device)
+        ops.ce_reduce(row_loss, labels, ignore_index, out)
+        return out[0], out, logits
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model: HipLlamaDecoder, tokens: Tensor, anchor: Tensor) -> Tensor:
+        hn = model._forward_hidden(tokens, save=True)
+        ctx.model, ctx.gen = model, model._fwd_generation
+        return hn
+
+    @staticmethod
+    def backward(ctx, d_hn: Tensor):
+        ctx.model._backward_hidden(d_hn.contiguous(), ctx.gen)
+        return None, None, torch.zeros_like(ctx.model._anchor)
+
+
+class _HeadLogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model: HipLlamaDecoder, hn: Tensor, anchor: Tensor) -> Tensor:
+        ctx.model = model
+        ctx.save_for_backward(hn)
+        return model._head_logits(hn)
+
+    @staticmethod
+    def backward(ctx, dlogits: Tensor):
+        (hn,) = ctx.saved_tensors
+        m = ctx.model
+        dl = dlogits
+        if not dl.is_contiguous() or dl.dtype != m.dtype:
+            dl = dl.to(m.dtype).contiguous()
+        return None, m._head_backward(dl, hn, None), torch.zeros_like(m._anchor)
+
+
+class _FusedLossFn(torch.autograd.Function):
+    """tokens, shifted labels -> scalar loss; backward runs head + decoder backward and accumulates into the flat
+    gradient buffer (so ``p.grad`` is populated exactly as after ``loss.backward()`` in the reference)."""
+
+    @staticmethod
+    def forward(ctx, model: HipLlamaDecoder, tokens: Tensor, labels: Tensor, ignore_index: int, anchor: Tensor) -> Tensor:
+        hn = model._forward_hidden(tokens, save=True)
+        loss, stats, dlogits = model._ce_forward(hn, labels, ignore_index, write_grad=True)
+        ctx.model, ctx.gen = model, model._fwd_generation
+        ctx.save_for_backward(hn, stats, dlogits)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        hn, stats, dlogits = ctx.saved_tensors
+        m = ctx.model
+        # d loss / d logits = (softmax - onehot) / n_valid ; the 1/n_valid and the upstream scalar ride in alpha_dev
+        alpha = (grad_out.to(torch.float32).reshape(1) / stats[2:3]).contiguous()
+        d_hn = m._head_backward(dlogits, hn, alpha)
+        m._backward_hidden(d_hn, ctx.gen)
+        return None, None, None, None, torch.zeros_like(m._anchor)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Reference-named entry point
+# --------------------------------------------------------------------------------------------------------------------
+def get_dtype(dtype: Any) -> torch.dtype:
+    if isinstance(dtype, torch.dtype):
+        return dtype
+    if dtype is None:
+        return torch.float32
+    if dtype not in PRECISION_STR_TO_DTYPE:
+        raise ValueError(f"Dtype {dtype} must be one of {', '.join(PRECISION_STR_TO_DTYPE)}")
+    return PRECISION_STR_TO_DTYPE[dtype]
+
+
+def get_device(device: Any = None) -> torch.device:
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        import os
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+    return dev
+
+
+def validate_expected_param_dtype(named_params, dtype: torch.dtype) -> None:
+    for name, param in named_params:
+        if param.dtype != dtype:
+            raise ValueError(f"Parameter {name} has dtype {param.dtype}, but expected {dtype}")
+
+
+def setup_llama3_2_1b(cfg, llama_config: ConfigLlama3_2, model_state_dict: Optional[dict[str, Any]],
+                      dtype_default: torch.dtype | str | None = None,
+                      device_default: torch.device | str | None = None) -> HipLlamaDecoder:
+    """Same signature and contract as ``/root/reference/ssi/model.py:18-39``: build the decoder from
+    ``llama_config.parameters`` in ``dtype_default`` on ``device_default``, load the (torchtune-key) state dict strictly,
+    check every parameter's dtype.  ``cfg.compile`` is accepted and ignored: there is no tracing compiler in this stack."""
+    if dtype_default is None:
+        dtype_default = torch.get_default_dtype()
+    elif isinstance(dtype_default, str):
+        dtype_default = get_dtype(cfg.dtype)
+    if device_default is None:
+        device_default = get_device(None)
+    elif isinstance(device_default, str):
+        device_default = get_device(cfg.device)
+    if cfg is not None and cfg.get("compile", False):
+        LOGGER.info("cfg.compile=true ignored: kernels are hand-written HIP, there is nothing to trace-compile")
+    model = HipLlamaDecoder(**llama_config.parameters, dtype=dtype_default, device=device_default)
+    if model_state_dict is not None:
+        model.load_state_dict(model_state_dict)
+    validate_expected_param_dtype(model.named_parameters(), dtype=dtype_default)
+    return model

@@ -1,0 +1,185 @@
+"""Tensor-level wrappers over the C ABI (``include/ssi_hip.h``).  Thin by design: shape checks on the host, raw device
+pointers and the current HIP stream across the ABI, no torch compute ops.  Every function raises on failure."""
+
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import GEMM_NN, GEMM_NT, GEMM_TN, check, dtype_code, ptr, stream_ptr
+
+__all__ = ["embed_fwd", "embed_bwd", "rmsnorm_fwd", "rmsnorm_bwd", "rope_", "attn_fwd", "attn_bwd", "swiglu_fwd",
+           "swiglu_bwd", "gemm", "ce_fwd", "ce_reduce", "count_tokens", "scale_", "sumsq", "adamw_step", "set_impl",
+           "GEMM_NT", "GEMM_NN", "GEMM_TN"]
+
+
+def set_impl(impl: int) -> int:
+    return _lib.load().ssi_set_impl(impl)
+
+
+def _byte_ws(nbytes: int, like: Tensor) -> Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
+
+
+def embed_fwd(tokens: Tensor, table: Tensor, out: Tensor, vocab: int) -> None:
+    n, dim = tokens.numel(), table.shape[1]
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and out.is_contiguous() and table.stride(1) == 1
+    assert table.stride(0) == dim and out.shape[-1] == dim and out.numel() == n * dim and out.dtype == table.dtype
+    check(_lib.load().ssi_embed_fwd(ptr(tokens), ptr(table), ptr(out), n, dim, vocab, dtype_code(table.dtype),
+                                    stream_ptr()), "ssi_embed_fwd")
+
+
+def embed_bwd(tokens: Tensor, dout: Tensor, dtable: Tensor, vocab: int, workspace: Tensor | None = None) -> None:
+    lib = _lib.load()
+    n, dim = tokens.numel(), dtable.shape[1]
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and dout.is_contiguous() and dtable.stride(0) == dim
+    need = lib.ssi_embed_bwd_workspace_bytes(vocab)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = _byte_ws(need, dout)
+    check(lib.ssi_embed_bwd(ptr(tokens), ptr(dout), ptr(dtable), n, dim, vocab, dtype_code(dtable.dtype), ptr(workspace),
+                            workspace.numel() * workspace.element_size(), stream_ptr()), "ssi_embed_bwd")
+
+
+def rmsnorm_fwd(x: Tensor, scale: Tensor, y: Tensor, rstd: Tensor | None, eps: float) -> None:
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    assert x.is_contiguous() and y.is_contiguous() and scale.is_contiguous() and scale.numel() == dim
+    assert rstd is None or (rstd.dtype == torch.float32 and rstd.numel() >= rows)
+    check(_lib.load().ssi_rmsnorm_fwd(ptr(x), ptr(scale), ptr(y), ptr(rstd), rows, dim, eps, dtype_code(x.dtype),
+                                      stream_ptr()), "ssi_rmsnorm_fwd")
+
+
+def rmsnorm_bwd_workspace_bytes(rows: int, dim: int) -> int:
+    return _lib.load().ssi_rmsnorm_bwd_workspace_bytes(rows, dim)
+
+
+def rmsnorm_bwd(dy: Tensor, x: Tensor, scale: Tensor, rstd: Tensor, dres: Tensor | None, dx: Tensor, dscale: Tensor,
+                workspace: Tensor | None = None) -> None:
+    lib = _lib.load()
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    assert dy.is_contiguous() and x.is_contiguous() and dx.is_contiguous() and dscale.is_contiguous()
+    assert dres is None or dres.is_contiguous()
+    need = lib.ssi_rmsnorm_bwd_workspace_bytes(rows, dim)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = _byte_ws(need, dy)
+    check(lib.ssi_rmsnorm_bwd(ptr(dy), ptr(x), ptr(scale), ptr(rstd), ptr(dres), ptr(dx), ptr(dscale), rows, dim,
+                              dtype_code(x.dtype), ptr(workspace), workspace.numel() * workspace.element_size(),
+                              stream_ptr()), "ssi_rmsnorm_bwd")
+
+
+def rope_(x: Tensor, seq_len: int, n_heads_rot: int, head_dim: int, table: Tensor, inverse: bool = False,
+          positions: Tensor | None = None) -> None:
+    """In-place rotation of the first ``n_heads_rot`` heads of each row of ``x`` ([rows, ld])."""
+    assert x.dim() == 2 and x.stride(1) == 1 and table.dtype == torch.float32 and table.is_contiguous()
+    assert positions is None or (positions.dtype == torch.int32 and positions.numel() == x.shape[0])
+    check(_lib.load().ssi_rope_inplace(ptr(x), x.stride(0), x.shape[0], seq_len, n_heads_rot, head_dim, ptr(table),
+                                       table.shape[0], ptr(positions), int(inverse), dtype_code(x.dtype), stream_ptr()),
+          "ssi_rope_inplace")
+
+
+def attn_fwd(qkv: Tensor, out: Tensor, lse: Tensor, batch: int, seq: int, n_heads: int, n_kv: int, head_dim: int) -> None:
+    assert qkv.dim() == 2 and qkv.stride(1) == 1 and out.is_contiguous() and lse.dtype == torch.float32
+    assert qkv.shape[0] == batch * seq and out.numel() == batch * seq * n_heads * head_dim
+    assert lse.numel() >= batch * n_heads * seq
+    check(_lib.load().ssi_attn_fwd(ptr(qkv), qkv.stride(0), ptr(out), ptr(lse), batch, seq, n_heads, n_kv, head_dim,
+                                   dtype_code(qkv.dtype), stream_ptr()), "ssi_attn_fwd")
+
+
+def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, dqkv: Tensor, delta: Tensor, batch: int, seq: int,
+             n_heads: int, n_kv: int, head_dim: int) -> None:
+    assert qkv.stride(1) == 1 and dqkv.stride() == qkv.stride() and out.is_contiguous() and dout.is_contiguous()
+    assert delta.dtype == torch.float32 and delta.numel() >= batch * n_heads * seq
+    check(_lib.load().ssi_attn_bwd(ptr(qkv), qkv.stride(0), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), batch,
+                                   seq, n_heads, n_kv, head_dim, dtype_code(qkv.dtype), stream_ptr()), "ssi_attn_bwd")
+
+
+def swiglu_fwd(gu: Tensor, act: Tensor) -> None:
+    inter = act.shape[-1]
+    rows = act.numel() // inter
+    assert gu.is_contiguous() and act.is_contiguous() and gu.shape[-1] == 2 * inter
+    check(_lib.load().ssi_swiglu_fwd(ptr(gu), ptr(act), rows, inter, dtype_code(gu.dtype), stream_ptr()), "ssi_swiglu_fwd")
+
+
+def swiglu_bwd(dact: Tensor, gu: Tensor, dgu: Tensor) -> None:
+    inter = dact.shape[-1]
+    rows = dact.numel() // inter
+    assert gu.is_contiguous() and dact.is_contiguous() and dgu.is_contiguous() and gu.shape[-1] == 2 * inter
+    check(_lib.load().ssi_swiglu_bwd(ptr(dact), ptr(gu), ptr(dgu), rows, inter, dtype_code(gu.dtype), stream_ptr()),
+          "ssi_swiglu_bwd")
+
+
+def gemm(layout: int, a: Tensor, b: Tensor, c: Tensor, *, residual: Tensor | None = None, alpha: float = 1.0,
+         alpha_dev: Tensor | None = None, accumulate: bool = False) -> None:
+    """c = (accumulate ? c : 0) + alpha * [*alpha_dev] * op(a) op(b) (+ residual).  2-D row-major operands."""
+    assert a.dim() == 2 and b.dim() == 2 and c.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and c.stride(1) == 1
+    assert a.dtype == b.dtype == c.dtype
+    M, N = c.shape
+    if layout == GEMM_NT:
+        K = a.shape[1]
+        assert a.shape[0] == M and b.shape == (N, K)
+    elif layout == GEMM_NN:
+        K = a.shape[1]
+        assert a.shape[0] == M and b.shape == (K, N)
+    else:
+        K = a.shape[0]
+        assert a.shape[1] == M and b.shape == (K, N)
+    if residual is not None:
+        assert residual.shape == c.shape and residual.stride() == c.stride() and residual.dtype == c.dtype
+    if alpha_dev is not None:
+        assert alpha_dev.dtype == torch.float32 and alpha_dev.numel() == 1
+    check(_lib.load().ssi_gemm(layout, M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(c), c.stride(0),
+                               ptr(residual), alpha, ptr(alpha_dev), int(accumulate), dtype_code(c.dtype), stream_ptr()),
+          "ssi_gemm")
+
+
+def ce_fwd(logits: Tensor, labels: Tensor, vocab: int, ignore_index: int, row_loss: Tensor, row_lse: Tensor | None,
+           write_grad: bool) -> None:
+    assert logits.dim() == 2 and logits.stride(1) == 1 and labels.dtype == torch.int64 and labels.is_contiguous()
+    rows = logits.shape[0]
+    assert labels.numel() == rows and row_loss.dtype == torch.float32 and row_loss.numel() >= rows
+    check(_lib.load().ssi_ce_fwd(ptr(logits), logits.stride(0), ptr(labels), rows, vocab, ignore_index, ptr(row_loss),
+                                 ptr(row_lse), int(write_grad), dtype_code(logits.dtype), stream_ptr()), "ssi_ce_fwd")
+
+
+def ce_reduce(row_loss: Tensor, labels: Tensor, ignore_index: int, out: Tensor) -> None:
+    assert out.dtype == torch.float32 and out.numel() >= 3 and labels.is_contiguous()
+    check(_lib.load().ssi_ce_reduce(ptr(row_loss), ptr(labels), labels.numel(), ignore_index, ptr(out), stream_ptr()),
+          "ssi_ce_reduce")
+
+
+def count_tokens(tokens: Tensor, labels: Tensor | None, ranges: Tensor, pad_id: int, ignore_index: int, out: Tensor) -> None:
+    """out[0:n_ranges] range counts, out[n_ranges] non-pad tokens, out[n_ranges+1] non-ignored labels (int64, device)."""
+    n_ranges = ranges.numel() // 2
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and ranges.dtype == torch.int64 and out.dtype == torch.int64
+    assert out.numel() >= n_ranges + 2 and (labels is None or (labels.is_contiguous() and labels.numel() == tokens.numel()))
+    check(_lib.load().ssi_count_tokens(ptr(tokens), ptr(labels), tokens.numel(), ptr(ranges), n_ranges, pad_id,
+                                       ignore_index, ptr(out), stream_ptr()), "ssi_count_tokens")
+
+
+def scale_(x: Tensor, scale: float = 1.0, scale_dev: Tensor | None = None) -> None:
+    assert x.is_contiguous()
+    check(_lib.load().ssi_scale_inplace(ptr(x), x.numel(), scale, ptr(scale_dev), dtype_code(x.dtype), stream_ptr()),
+          "ssi_scale_inplace")
+
+
+def sumsq(x: Tensor, out: Tensor, workspace: Tensor | None = None) -> None:
+    lib = _lib.load()
+    assert x.is_contiguous() and out.dtype == torch.float32
+    need = lib.ssi_sumsq_workspace_bytes(x.numel())
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = _byte_ws(need, x)
+    check(lib.ssi_sumsq(ptr(x), x.numel(), dtype_code(x.dtype), ptr(out), ptr(workspace),
+                        workspace.numel() * workspace.element_size(), stream_ptr()), "ssi_sumsq")
+
+
+def adamw_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, *, lr: float, beta1: float, beta2: float,
+               eps: float, weight_decay: float, step: int, grad_scale_dev: Tensor | None = None,
+               zero_grad: bool = False) -> None:
+    assert param.is_contiguous() and grad.is_contiguous() and exp_avg.is_contiguous() and exp_avg_sq.is_contiguous()
+    assert param.numel() == grad.numel() == exp_avg.numel() == exp_avg_sq.numel()
+    assert param.dtype == grad.dtype == exp_avg.dtype == exp_avg_sq.dtype
+    check(_lib.load().ssi_adamw_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, beta1, beta2,
+                                     eps, weight_decay, step, ptr(grad_scale_dev), int(zero_grad), dtype_code(param.dtype),
+                                     stream_ptr()), "ssi_adamw_step")

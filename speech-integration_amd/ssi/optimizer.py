@@ -1,0 +1,142 @@
+"""Optimizer of the training step (reference: ``/root/reference/ssi/optimizer.py:8-17``, ``conf/training.yaml:2-10``).
+
+``setup_optimizer(cfg, model, optimizer_state_dict)`` keeps the reference signature.  :class:`HipAdamW` is a
+``torch.optim.Optimizer`` (so ``LambdaLR``, ``param_groups``, ``state_dict`` work unchanged) whose ``step`` is ONE HIP
+kernel over the model's flat parameter / gradient / moment buffers: decoupled weight decay, fp32 op-math, a single
+rounding on store — the semantics of ``torch.optim.AdamW(fused=True)`` (K13), with ``scale_grads`` (K11) and the
+clip coefficient (K12) folded in as a device-side gradient multiplier and the gradient buffer zeroed in the same pass."""
+
+from __future__ import annotations
+
+from typing import Any, Iterable
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+
+class HipAdamW(torch.optim.Optimizer):
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas: tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-2, amsgrad: bool = False, fused: bool | None = None, *, model=None, **unused: Any):
+        if amsgrad:
+            raise NotImplementedError("amsgrad=True is not supported (reference default: false, conf/training.yaml:8)")
+        if unused:
+            raise TypeError(f"unsupported AdamW arguments: {sorted(unused)}")
+        if model is None or not hasattr(model, "_flat"):
+            raise TypeError("HipAdamW needs model=<HipLlamaDecoder> (flat parameter buffers)")
+        defaults = dict(lr=float(lr), betas=tuple(float(b) for b in betas), eps=float(eps), weight_decay=float(weight_decay),
+                        amsgrad=False, fused=True)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("one param group expected (the reference passes model.parameters())")
+        self.model = model
+        self._exp_avg = torch.zeros_like(model._flat)
+        self._exp_avg_sq = torch.zeros_like(model._flat)
+        self._step_count = 0
+        self._views_ready = False
+
+    def _ensure_state_views(self) -> None:
+        if self._views_ready:
+            return
+        m = self.model
+        for p, name, rows in m._param_src:
+            self.state[p] = {
+                "step": torch.tensor(float(self._step_count)),
+                "exp_avg": m._view(name, rows, self._exp_avg),
+                "exp_avg_sq": m._view(name, rows, self._exp_avg_sq),
+            }
+        self._views_ready = True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        m = self.model
+        self._step_count += 1
+        ops.adamw_step(m._flat, m._flat_grad, self._exp_avg, self._exp_avg_sq, lr=float(g["lr"]), beta1=g["betas"][0],
+                       beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], step=self._step_count,
+                       grad_scale_dev=m.pending_grad_scale, zero_grad=True)
+        m.pending_grad_scale = None
+        m._grads_dirty = False
+        if self._views_ready:
+            for st in self.state.values():
+                st["step"].fill_(float(self._step_count))
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        # the fused step already zeroed the buffer when it ran; zero again only if gradients are pending
+        self.model.zero_grad(set_to_none=set_to_none)
+
+    def state_dict(self):
+        self._ensure_state_views()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict) -> None:
+        self._ensure_state_views()
+        super().load_state_dict(state_dict)
+        m = self.model
+        step = 0
+        for p, name, rows in m._param_src:  # re-home the loaded moments in the flat buffers
+            st = self.state[p]
+            ea, es = m._view(name, rows, self._exp_avg), m._view(name, rows, self._exp_avg_sq)
+            ea.copy_(st["exp_avg"])
+            es.copy_(st["exp_avg_sq"])
+            st["exp_avg"], st["exp_avg_sq"] = ea, es
+            step = int(float(st["step"]))
+            st["step"] = torch.tensor(float(step))
+        self._step_count = step
+
+
+def _to_container(node):
+    try:
+        from .config import DictConfig, OmegaConf
+        if isinstance(node, DictConfig):
+            return OmegaConf.to_container(node, resolve=True)
+    except Exception:  # pragma: no cover
+        pass
+    try:
+        from omegaconf import OmegaConf as _OC  # type: ignore
+        return _OC.to_container(node, resolve=True)
+    except Exception:
+        return dict(node)
+
+
+def setup_optimizer(cfg, model, optimizer_state_dict: dict[str, Any] | None = None) -> torch.optim.Optimizer:
+    optimizer_kwargs = _to_container(cfg.optimizer)
+    if hasattr(model, "_flat"):
+        optimizer = HipAdamW(model.parameters(), model=model, **optimizer_kwargs)
+    else:  # foreign module (tests with stand-in models): the reference's own choice
+        optimizer_kwargs.pop("fused", None)
+        optimizer = torch.optim.AdamW(model.parameters(), **optimizer_kwargs)
+    if optimizer_state_dict is not None:
+        optimizer.load_state_dict(optimizer_state_dict)
+    return optimizer
+
+
+def scale_grads(model, scaler: Tensor | float) -> None:
+    """torchtune ``training.scale_grads`` (``trainer.py:404``): ``p.grad *= scaler`` for every parameter.  On the HIP
+    decoder the multiplication is deferred: it is folded into the optimizer kernel (and into the clip norm), saving a
+    full read+write pass over the 2.5 GB gradient buffer."""
+    if hasattr(model, "_flat_grad"):
+        s = torch.as_tensor(scaler, dtype=torch.float32).reshape(1).to(model._flat_grad.device, non_blocking=True)
+        model.pending_grad_scale = s if model.pending_grad_scale is None else model.pending_grad_scale * s
+        return
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad *= scaler.to(p.grad.device) if isinstance(scaler, Tensor) else scaler
+
+
+def clip_grad_norm_(model, max_norm: float) -> Tensor:
+    """``torch.nn.utils.clip_grad_norm_`` (``trainer.py:405-408``) on the flat gradient buffer: L2 norm by the HIP
+    two-stage reduction, clip coefficient ``min(1, max_norm / (norm + 1e-6))`` folded into the pending gradient scale.
+    Returns the total norm (device tensor, of the scaled gradients)."""
+    if not hasattr(model, "_flat_grad"):
+        return torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=float(max_norm))
+    out = torch.empty(1, dtype=torch.float32, device=model._flat_grad.device)
+    ops.sumsq(model._flat_grad, out)
+    scale = model.pending_grad_scale if model.pending_grad_scale is not None else torch.ones_like(out)
+    total_norm = out.sqrt() * scale.abs()
+    coef = torch.clamp(float(max_norm) / (total_norm + 1e-6), max=1.0)
+    model.pending_grad_scale = scale * coef
+    return total_norm.reshape(())

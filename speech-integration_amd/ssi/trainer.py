@@ -1,0 +1,438 @@
+"""Stateful trainer for the speech-integration hot path on MI355X.
+
+Mirrors the public surface of ``/root/reference/ssi/trainer.py`` (``Trainer``, ``TrainingGeometry``, the method names and
+the attributes its tests assert) and reproduces its step algebra exactly (``:385-424``; SURVEY.md
+Appendix A.5): each micro-batch's mean loss over SHIFTED valid labels is multiplied by the UNSHIFTED valid-label count
+before ``backward``; at the accumulation boundary gradients are divided by the sum of unshifted counts.
+
+What differs underneath (MI355X-first):
+* one fused HIP kernel counts token types and valid labels (K14); together with the loss it is fetched with ONE
+  device->host copy per micro-batch, issued after backward has been queued (the reference blocks 7-8 times per
+  micro-batch, before and after the forward);
+* ``scale_grads`` and the clip coefficient are folded into the single-kernel AdamW step, which also zeroes the gradients;
+* data parallelism (absent from the reference): per-layer gradient buckets all-reduced over RCCL/xGMI on a side stream
+  during the last micro-batch's backward; token counts and running loss reduced with one small collective; every rank
+  divides by the GLOBAL token count.
+"""
+
+from __future__ import annotations
+
+import copy
+import itertools
+import logging
+import math
+import os
+import random
+import time
+from collections import defaultdict
+from dataclasses import dataclass
+from typing import Any
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import __version__
+from .constants import DEBUGGING_TAG, MODEL_KEY, SEED
+from .distributed import GradSync, all_reduce_scalars, get_world_size_and_rank, init_distributed
+from .eval import batch_to_device, compute_dataset_loss
+from .llama_configs import configllama3_2_1b
+from .loss import CEWithChunkedOutputLoss, compute_loss
+from .lr_schedule import get_lr, setup_lr_scheduler
+from .metric_logging import WandBLoggerPatched as WandBLogger
+from .model import get_device, get_dtype, setup_llama3_2_1b
+from .optimizer import clip_grad_norm_, scale_grads, setup_optimizer
+from .train_utils import (count_token_types, count_token_types_async, get_token_type_ranges, resume_training_state,
+                          validate_resume_hparams, validate_train_cfg)
+
+__all__ = ["Trainer", "TrainingGeometry"]
+
+LOGGER = logging.getLogger(__name__)
+
+
+def _to_yaml(cfg) -> str:
+    try:
+        from .config import DictConfig, OmegaConf
+        if isinstance(cfg, DictConfig):
+            return OmegaConf.to_yaml(cfg, resolve=True, sort_keys=False)
+    except Exception:
+        pass
+    try:
+        from omegaconf import OmegaConf as _OC  # type: ignore
+        return _OC.to_yaml(cfg, resolve=True, sort_keys=False)
+    except Exception:
+        return str(cfg)
+
+
+def set_seed(seed: int, debug_mode: Any = None) -> None:
+    """torchtune ``training.set_seed``: seed python / numpy / torch (+ per-rank offset is NOT applied: the reference seeds
+    every process identically and shards data with ``DistributedSampler``)."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if debug_mode is not None:
+        mode = {"default": 0, "warn": 1, "error": 2}.get(debug_mode, debug_mode)
+        torch.set_deterministic_debug_mode(int(mode))
+
+
+@dataclass(frozen=True)
+class TrainingGeometry:
+    """Constants derived from dataset size and gradient accumulation (``trainer.py:64-125``)."""
+
+    batch_size: int
+    batches_per_epoch: int
+    steps_per_epoch: int
+    usable_batches: int
+    n_epochs: int
+    gradient_accumulation_steps: int
+    world_size: int
+
+    @classmethod
+    def from_config(cls, cfg, dataloader, world_size: int) -> "TrainingGeometry":
+        batch_size = cfg.data.train.dataloader.batch_size
+        batches_per_epoch = len(dataloader)
+        ga = cfg.gradient_accumulation_steps
+        remainder = batches_per_epoch % ga
+        if remainder > 0:
+            LOGGER.warning(f"batches_per_epoch ({batches_per_epoch}) is not divisible by gradient_accumulation_steps ({ga}): "
+                           f"{remainder} remainder batches will be discarded at each epoch boundary.")
+        steps_per_epoch = batches_per_epoch // ga
+        if steps_per_epoch <= 0:
+            raise ValueError(f"batches_per_epoch ({batches_per_epoch}) < gradient_accumulation_steps ({ga})")
+        return cls(batch_size=batch_size, batches_per_epoch=batches_per_epoch, steps_per_epoch=steps_per_epoch,
+                   usable_batches=steps_per_epoch * ga, n_epochs=math.ceil(cfg.max_steps / steps_per_epoch),
+                   gradient_accumulation_steps=ga, world_size=world_size)
+
+
+class Trainer:
+    """Usage (as the reference): ``t = Trainer(cfg); t.setup(); t.train(); t.cleanup()``."""
+
+    def __init__(self, cfg) -> None:
+        self.cfg = cfg
+        # components — populated by setup()
+        self.model = None
+        self.tokenizer = None
+        self.optimizer = None
+        self.lr_scheduler = None
+        self.loss_fn = None
+        self.checkpointer = None
+        self.wandb_logger = None
+        # data
+        self.data_train = None
+        self.sampler_train = None
+        self.data_dev = None
+        self.token_type_ranges: dict[str, tuple[int, int]] | None = None
+        self.geometry: TrainingGeometry | None = None
+        # device / dtype
+        self.device: torch.device | None = None
+        self.dtype: torch.dtype | None = None
+        self.world_size: int | None = None
+        self.rank: int = 0
+        # training state
+        self.global_step: int = 0
+        self.consumed_samples: int = 0
+        self.tokens_train_total: int = 0
+        self.token_type_counts_total: defaultdict[str, int] = defaultdict(int)
+        self.wall_clock_offset: float = 0.0
+        # step-level accumulators
+        self.loss_running: float = 0.0
+        self.num_tokens_step: int = 0
+        self.max_seq_len_step: int = 0
+        self.t_train_start: float = 0.0
+        self.t_step_start: float = 0.0
+        self._grad_norm: float | None = None
+        self._loss_log: list[float] | None = None
+        # data parallel
+        self.grad_sync: GradSync | None = None
+        self._resume_state: dict[str, Any] | None = None
+        self._resume_rng_state = None
+
+    # === Setup ===========================================================================================================
+    def setup(self) -> None:
+        validate_train_cfg(self.cfg)
+        set_seed(seed=SEED, debug_mode=self.cfg.get("debug_mode"))
+        self.device = get_device(self.cfg.device)
+        self.dtype = get_dtype(self.cfg.dtype)
+        self.world_size, self.rank = init_distributed(self.device)
+        self._setup_logging()
+        self._setup_model()
+        self._setup_tokenizer()
+        self._extract_resume_state()
+        self._setup_optimizer()
+        self._setup_loss()
+        self._setup_data()
+        self.geometry = TrainingGeometry.from_config(self.cfg, self.data_train, self.world_size)
+        self._finalize_resume()
+        self._setup_data_parallel()
+        self._ckpt_dict = None
+        self._resume_rng_state = self._resume_state.pop("rng_state", None) if self._resume_state else None
+        self._resume_state = None
+
+    def _setup_logging(self) -> None:
+        tags = [__version__, self.cfg.config_name]
+        if os.getenv("SLURM_JOB_QOS") == "gpu-debug":
+            tags += [DEBUGGING_TAG]
+        wandb_cfg = {k: self.cfg.wandb[k] for k in self.cfg.wandb} if self.cfg.get("wandb") is not None else {}
+        self.wandb_logger = WandBLogger(**wandb_cfg, tags=tags)
+        if self.cfg.checkpointer.get("output_dir") is None:
+            from .checkpoint import resolve_checkpointer_output_dir
+            self.cfg.checkpointer.output_dir = resolve_checkpointer_output_dir(self.cfg, self.wandb_logger)
+            LOGGER.info(f"No checkpointer output dir provided. Resolved to: {self.cfg.checkpointer.output_dir!s}")
+
+    def _setup_model(self) -> None:
+        from .checkpoint import TuneCheckpointer
+        self._llama_config = copy.deepcopy(configllama3_2_1b)
+        self._llama_config.update_from_speech_cfg(self.cfg.speech)
+        overrides = self.cfg.get("model_overrides")  # test/bench hook: shrink the architecture, never used by conf/
+        if overrides is not None:
+            for k in overrides:
+                setattr(self._llama_config, k, overrides[k])
+        ck = {k: self.cfg.checkpointer[k] for k in self.cfg.checkpointer}
+        self.checkpointer = TuneCheckpointer(**ck, model_expectations=self._llama_config.checkpoint_expectations)
+        self._ckpt_dict = self.checkpointer.load_checkpoint()
+        self.model = setup_llama3_2_1b(cfg=self.cfg, llama_config=self._llama_config,
+                                       model_state_dict=self._ckpt_dict.get(MODEL_KEY), dtype_default=self.dtype,
+                                       device_default=self.device)
+        if self._ckpt_dict.get(MODEL_KEY) is None:
+            from .checkpoint import random_init_
+            random_init_(self.model, seed=SEED)
+        self.model.to(device=self.device)
+        self.model.train()
+
+    def _setup_tokenizer(self) -> None:
+        from .tokenizer import setup_llama3_tokenizer
+        tk = {k: self.cfg.tokenizer[k] for k in self.cfg.tokenizer}
+        self.tokenizer, _special = setup_llama3_tokenizer(**tk, llama_config=self._llama_config)
+        self.token_type_ranges = get_token_type_ranges(llama_config=self._llama_config)
+
+    def _setup_data(self) -> None:
+        from .data import setup_synthetic_data
+        for split in ("train", "dev"):
+            node = self.cfg.data[split]
+            if node.dataset.get("source") != "synthetic":
+                raise NotImplementedError(
+                    f"data.{split}.dataset.source={node.dataset.get('source')!r}: the HF-datasets/tiktoken pipeline of the "
+                    "reference (ssi/data/*) is outside this build's hot-path scope; use source=synthetic (MLS-shaped DSU "
+                    "sequences) or inject dataloaders via Trainer.data_train / Trainer.data_dev")
+            loader, sampler = setup_synthetic_data(
+                n_samples=int(node.dataset.get("n_samples") or 1024), seq_len=int(self.cfg.tokenizer.max_seq_len),
+                batch_size=int(node.dataloader.batch_size), n_dsus=int(self.cfg.speech.n_dsus), world_size=self.world_size,
+                rank=self.rank, shuffle=bool(node.get("shuffle", False)), drop_last=bool(node.dataloader.get("drop_last", False)),
+                fixed_len=bool(node.dataset.get("fixed_len", True)), kind=str(self.cfg.config_name))
+            if split == "train":
+                self.data_train, self.sampler_train = loader, sampler
+            else:
+                self.data_dev = loader
+
+    def _extract_resume_state(self) -> None:
+        self._resume_state = None
+        if getattr(self.checkpointer, "training_state_checkpoint", None) is not None:
+            self._resume_state = resume_training_state(self._ckpt_dict)
+            self.global_step = self._resume_state["global_step"]
+            self.consumed_samples = self._resume_state["consumed_samples"]
+
+    def _setup_optimizer(self) -> None:
+        self.optimizer = setup_optimizer(self.cfg, self.model, self._resume_state["optimizer_state"] if self._resume_state else None)
+        self.lr_scheduler = setup_lr_scheduler(cfg=self.cfg, optimizer=self.optimizer, global_step=self.global_step - 1,
+                                               num_training_steps=self.cfg.max_steps)
+        if self._resume_state and self.lr_scheduler is not None:
+            self.lr_scheduler.load_state_dict(self._resume_state["lr_scheduler_state"])
+
+    def _setup_loss(self) -> None:
+        self.loss_fn = CEWithChunkedOutputLoss()
+        if isinstance(self.loss_fn, CEWithChunkedOutputLoss):
+            self.model.set_num_output_chunks(self.loss_fn.num_output_chunks)
+
+    def _finalize_resume(self) -> None:
+        if self._resume_state is None:
+            return
+        cm = self._resume_state["cumulative_metrics"]
+        self.tokens_train_total = cm["tokens_train_total"]
+        for k, v in cm["token_type_counts"].items():
+            self.token_type_counts_total[k] = v
+        self.wall_clock_offset = cm["wall_clock_seconds"]
+        validate_resume_hparams(
+            ckpt_hparams=self._resume_state["training_hparams"],
+            current_hparams={"batch_size": self.geometry.batch_size,
+                             "gradient_accumulation_steps": self.cfg.gradient_accumulation_steps,
+                             "world_size": self.world_size, "steps_per_epoch": self.geometry.steps_per_epoch},
+            force_resume=self.cfg.get("force_resume", False))
+
+    def _setup_data_parallel(self) -> None:
+        """One process per GPU; gradients exchanged per bucket during backward (``ssi.distributed``)."""
+        if not self.world_size or self.world_size <= 1 or self.model is None:
+            return
+        if hasattr(self.model, "_flat_grad"):
+            self.grad_sync = GradSync(self.model._flat_grad, self.model.buckets)
+            self.model.grad_sync = self.grad_sync
+        else:
+            self.grad_sync = GradSync.for_module(self.model)
+
+    # === Training ========================================================================================================
+    def train(self) -> None:
+        self.optimizer.zero_grad()
+        self.t_train_start = time.perf_counter()
+        self.t_step_start = time.perf_counter()
+        self._reset_step_accumulators()
+        epochs_run = self.global_step // self.geometry.steps_per_epoch
+        batches_to_skip = (self.global_step % self.geometry.steps_per_epoch) * self.cfg.gradient_accumulation_steps
+        if self._resume_rng_state is not None:
+            from .checkpoint import restore_rng_states
+            restore_rng_states(self._resume_rng_state)
+            LOGGER.info("Restored framework RNG states from checkpoint.")
+            self._resume_rng_state = None
+        LOGGER.info(_to_yaml(self.cfg))
+        self.wandb_logger.log_config(self.cfg)
+        for epoch in range(epochs_run, self.geometry.n_epochs):
+            self._train_epoch(epoch, batches_to_skip if epoch == epochs_run else 0)
+            if self.global_step >= self.cfg.max_steps:
+                LOGGER.info("Training completed.")
+                return
+
+    def _train_epoch(self, epoch: int, batches_to_skip: int = 0) -> None:
+        if self.sampler_train is not None:
+            self.sampler_train.set_epoch(epoch)
+        if hasattr(self.data_train.dataset, "set_epoch"):
+            self.data_train.dataset.set_epoch(epoch)
+        if batches_to_skip > 0:
+            LOGGER.info(f"Resuming: skipping {batches_to_skip} batches in epoch {epoch}")
+            data_iter = itertools.islice(enumerate(self.data_train), batches_to_skip, self.geometry.usable_batches)
+        else:
+            data_iter = itertools.islice(enumerate(self.data_train), self.geometry.usable_batches)
+        ga = self.cfg.gradient_accumulation_steps
+        for i, batch in data_iter:
+            boundary = (i + 1) % ga == 0
+            self._train_step(batch, sync_gradients=boundary)
+            if boundary:
+                self._optimizer_step(epoch, i)
+                if self.global_step >= self.cfg.max_steps:
+                    return
+            del batch
+
+    def _train_step(self, batch: dict[str, Tensor], sync_gradients: bool = True) -> None:
+        """Single micro-batch forward + backward (``trainer.py:385-395``) with one host sync at the end."""
+        batch_to_device(batch, self.device)
+        tokens, labels = batch["tokens"], batch["labels"]
+        ignore = self.loss_fn.ignore_index
+        self.max_seq_len_step = max(self.max_seq_len_step, tokens.size(1))
+        on_gpu = tokens.is_cuda
+        if on_gpu:  # K14: ranges + non-pad + valid labels in one launch, result stays on the device
+            counts_dev = count_token_types_async(tokens, self.token_type_ranges, self.tokenizer.pad_id, labels, ignore)
+            n_valid = counts_dev[-1]
+        else:       # host tensors (stand-in models in CPU tests)
+            counts_host = count_token_types(tokens, self.token_type_ranges, self.tokenizer.pad_id)
+            n_valid = (labels != ignore).sum()
+        if hasattr(self.model, "sync_this_backward"):
+            self.model.sync_this_backward = bool(sync_gradients)
+        loss_batch = compute_loss(batch, self.model, self.loss_fn) * n_valid  # mean over SHIFTED x UNSHIFTED count
+        loss_batch.backward()
+        if on_gpu:
+            host = torch.cat((counts_dev.to(torch.float64), loss_batch.detach().to(torch.float64).reshape(1))).tolist()
+            names = list(self.token_type_ranges) + ["total"]
+            for tt, c in zip(names, host):
+                self.token_type_counts_total[tt] += int(c)
+            num_tokens_iter, loss_value = int(host[len(names)]), float(host[-1])
+        else:
+            for tt, c in counts_host.items():
+                self.token_type_counts_total[tt] += c
+            num_tokens_iter, loss_value = int(n_valid.item()), float(loss_batch.item())
+        self.num_tokens_step += num_tokens_iter
+        self.loss_running += loss_value
+
+    def _optimizer_step(self, epoch: int, iter_idx: int) -> None:
+        """Accumulation boundary (``trainer.py:397-424``): [all-reduce] -> scale -> clip -> AdamW -> LR -> counters."""
+        if self.grad_sync is not None:
+            self.grad_sync.finish()
+            self.num_tokens_step, self.loss_running = (
+                lambda v: (int(round(v[0])), float(v[1])))(all_reduce_scalars([self.num_tokens_step, self.loss_running], self.device))
+        if self.num_tokens_step == 0:
+            LOGGER.warning("No non-ignored tokens in accumulation window; skipping optimizer step.")
+            self.optimizer.zero_grad(set_to_none=True)
+            self._reset_step_accumulators()
+            return
+        scale_grads(self.model, torch.tensor(1 / self.num_tokens_step))
+        if self.cfg.clip_grad_norm is not None:
+            self._grad_norm = clip_grad_norm_(self.model, max_norm=float(self.cfg.clip_grad_norm))
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        self.global_step += 1
+        self.consumed_samples += self.cfg.gradient_accumulation_steps * self.geometry.batch_size * self.world_size
+        loss_to_log = self.loss_running / self.num_tokens_step
+        self.tokens_train_total += self.num_tokens_step
+        if self._loss_log is not None:
+            self._loss_log.append(loss_to_log)
+        self._log_metrics(epoch, iter_idx, loss_to_log)
+        self._reset_step_accumulators()
+        self._maybe_save_checkpoint()
+
+    def _evaluate(self) -> float:
+        return compute_dataset_loss(self.model, self.data_dev, self.loss_fn,
+                                    epoch=self.global_step // self.geometry.steps_per_epoch, global_step=self.global_step,
+                                    steps_per_epoch=self.geometry.steps_per_epoch, device=self.device)
+
+    def _log_metrics(self, epoch: int, iter_idx: int, loss_to_log: float) -> None:
+        LOGGER.info(" | ".join((
+            f"Epoch {epoch + 1:03d}",
+            f"Iteration {iter_idx:0{len(str(self.geometry.batches_per_epoch))}d} / {self.geometry.batches_per_epoch}",
+            f"Global Step {self.global_step}", f"Loss: {loss_to_log:.4f}", f"Tokens (num_tokens_step): {self.num_tokens_step}",
+            *[f"Tokens ({tt}): {c}" for tt, c in self.token_type_counts_total.items()])))
+        dev_loss = self._evaluate() if self.global_step % self.cfg.eval_steps == 0 else None
+        if self.global_step % self.cfg.log_interval == 0:
+            dur_step = time.perf_counter() - self.t_step_start
+            log_dict = {
+                "loss": loss_to_log,
+                "lr": get_lr(self.optimizer),
+                "duration_step": dur_step,
+                "tokens_per_second_per_gpu": self.num_tokens_step / dur_step / max(1, self.world_size if self.grad_sync else 1),
+                "tokens_total": self.tokens_train_total,
+                "train_clock_time": (self.wall_clock_offset + (time.perf_counter() - self.t_train_start)) / (60**2),
+                "max_seq_len_step": self.max_seq_len_step,
+                **{f"n_tokens.{tt}": c for tt, c in self.token_type_counts_total.items()},
+            }
+            if self.cfg.clip_grad_norm is not None:
+                log_dict["grad_norm"] = float(self._grad_norm) if self._grad_norm is not None else None
+            if dev_loss is not None:
+                log_dict["dev_loss"] = dev_loss
+            if self.rank == 0:
+                self.wandb_logger.log_dict(log_dict, step=self.global_step)
+
+    def _maybe_save_checkpoint(self) -> None:
+        if self.global_step != 0 and self.global_step % self.cfg.save_steps == 0:
+            self.save_checkpoint()
+            LOGGER.info(f"Checkpoint saved at step {self.global_step}")
+
+    def _reset_step_accumulators(self) -> None:
+        self.loss_running = 0.0
+        self.num_tokens_step = 0
+        self.max_seq_len_step = 0
+        self.t_step_start = time.perf_counter()
+
+    # === Checkpointing ===================================================================================================
+    def save_checkpoint(self) -> None:
+        if self.rank != 0:
+            return
+        self.checkpointer.save_model_checkpoint(self.model.state_dict(), self.global_step)
+        self.checkpointer.save_training_state(
+            optimizer_state_dict=self.optimizer.state_dict(),
+            lr_scheduler_state_dict=self.lr_scheduler.state_dict() if self.lr_scheduler else None,
+            global_step=self.global_step,
+            seed=SEED,
+            training_hparams={"batch_size": self.geometry.batch_size,
+                              "gradient_accumulation_steps": self.cfg.gradient_accumulation_steps,
+                              "world_size": self.world_size, "steps_per_epoch": self.geometry.steps_per_epoch},
+            consumed_samples=self.consumed_samples,
+            cumulative_metrics={"tokens_train_total": self.tokens_train_total,
+                                "token_type_counts": dict(self.token_type_counts_total),
+                                "wall_clock_seconds": self.wall_clock_offset + (time.perf_counter() - self.t_train_start)},
+        )
+
+    # === Cleanup =========================================================================================================
+    def cleanup(self) -> None:
+        if getattr(self, "wandb_logger", None) is not None:
+            self.wandb_logger.close()
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and self.world_size and self.world_size > 1:
+            dist.barrier()
+            dist.destroy_process_group()

@@ -1,0 +1,332 @@
+"""GPU parity tests, one per kernel family of the C ABI (include/ssi_hip.h), against the CPU oracle / plain torch fp32 on
+the same seeded inputs.  Integer results bit-exact; fp32 storage within 1e-5 relative; bf16 storage within bf16 rounding
+of the fp32 result (tolerances written at each assert)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ssi import ops as o
+    return o
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,dim", [(5, 128), (1024, 2048), (3, 256)])
+def test_rmsnorm_fwd_bwd(ops, dtype, rows, dim):
+    from oracle.llama_oracle import RMSNorm
+    x = rnd(rows, dim, dtype=dtype, seed=1)
+    w = (1 + 0.1 * rnd(dim, seed=2)).to(dtype)
+    dy = rnd(rows, dim, dtype=dtype, seed=3)
+    dres = rnd(rows, dim, dtype=dtype, seed=4)
+    ref = RMSNorm(dim, 1e-5)
+    ref.scale.data = w.clone()
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy)
+    xg, wg, dyg = x.to(DEV), w.to(DEV), dy.to(DEV)
+    y = torch.empty_like(xg)
+    rstd = torch.empty(rows, dtype=torch.float32, device=DEV)
+    ops.rmsnorm_fwd(xg, wg, y, rstd, 1e-5)
+    torch.testing.assert_close(y.cpu().float(), yr.detach().float(), **tol(dtype))
+    torch.testing.assert_close(rstd.cpu(), torch.rsqrt(x.float().pow(2).mean(-1) + 1e-5), rtol=1e-5, atol=1e-6)
+    dx = torch.empty_like(xg)
+    dscale = torch.zeros(dim, dtype=dtype, device=DEV)
+    ops.rmsnorm_bwd(dyg, xg, wg, rstd, dres.to(DEV), dx, dscale)
+    t = tol(dtype)
+    torch.testing.assert_close(dx.cpu().float(), (xr.grad + dres).float(), rtol=t["rtol"], atol=max(t["atol"], 3e-5 if dtype == torch.float32 else 6e-2))
+    torch.testing.assert_close(dscale.cpu().float(), ref.scale.grad.float(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-4,
+                               atol=1e-4 * rows if dtype == torch.float32 else 0.05 * math.sqrt(rows))
+    # accumulation into dscale + determinism
+    d2 = dscale.clone()
+    ops.rmsnorm_bwd(dyg, xg, wg, rstd, None, dx, d2)
+    if dtype == torch.float32:
+        torch.testing.assert_close(d2.cpu(), 2 * dscale.cpu(), rtol=1e-5, atol=1e-5)
+    d3 = dscale.clone()
+    ops.rmsnorm_bwd(dyg, xg, wg, rstd, None, dx, d3)
+    assert torch.equal(d2, d3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rope_matches_oracle_and_inverts(ops, dtype):
+    from oracle.llama_oracle import apply_rope, llama3_scaled_theta, rope_cache
+    from ssi.model import llama3_rope_table
+    B, S, H, KV, hd = 2, 37, 4, 2, 64
+    table = llama3_rope_table(hd, 128)
+    torch.testing.assert_close(table, rope_cache(llama3_scaled_theta(hd), 128), rtol=0, atol=0)
+    qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=dtype, seed=5)
+    ref = qkv.clone().view(B, S, H + 2 * KV, hd)
+    ref[:, :, : H + KV] = apply_rope(ref[:, :, : H + KV], table)
+    x = qkv.to(DEV)
+    ops.rope_(x, S, H + KV, hd, table.to(DEV))
+    torch.testing.assert_close(x.cpu().float(), ref.reshape(B * S, -1).float(), rtol=1e-6, atol=1e-6 if dtype == torch.float32 else 8e-3)
+    assert torch.equal(x.cpu()[:, (H + KV) * hd:], qkv[:, (H + KV) * hd:])  # v heads untouched
+    ops.rope_(x, S, H + KV, hd, table.to(DEV), inverse=True)
+    torch.testing.assert_close(x.cpu().float(), qkv.float(), rtol=1e-5, atol=1e-5 if dtype == torch.float32 else 3e-2)
+    # explicit positions == implicit row % S
+    pos = (torch.arange(B * S) % S).to(torch.int32).to(DEV)
+    x1, x2 = qkv.to(DEV), qkv.to(DEV)
+    ops.rope_(x1, S, H + KV, hd, table.to(DEV))
+    ops.rope_(x2, S, H + KV, hd, table.to(DEV), positions=pos)
+    assert torch.equal(x1, x2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_swiglu_fwd_bwd(ops, dtype):
+    rows, inter = 33, 512
+    gu = rnd(rows, 2 * inter, dtype=dtype, seed=6, scale=2.0)
+    da = rnd(rows, inter, dtype=dtype, seed=7)
+    gr = gu.clone().requires_grad_(True)
+    act_ref = F.silu(gr[:, :inter]) * gr[:, inter:]
+    act_ref.backward(da)
+    act = torch.empty(rows, inter, dtype=dtype, device=DEV)
+    ops.swiglu_fwd(gu.to(DEV), act)
+    torch.testing.assert_close(act.cpu().float(), act_ref.detach().float(), **tol(dtype))
+    dgu = torch.empty(rows, 2 * inter, dtype=dtype, device=DEV)
+    ops.swiglu_bwd(da.to(DEV), gu.to(DEV), dgu)
+    torch.testing.assert_close(dgu.cpu().float(), gr.grad.float(), rtol=tol(dtype)["rtol"], atol=1e-5 if dtype == torch.float32 else 6e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embedding_gather_and_deterministic_scatter(ops, dtype):
+    V, D, T = 515, 256, 1000
+    table = rnd(V, D, dtype=dtype, seed=8)
+    g = torch.Generator().manual_seed(9)
+    tok = torch.randint(0, V, (T,), generator=g)
+    tok[100:400] = 7          # a heavily repeated id (pad-like) spanning several 64-wide scan chunks
+    tok[-1] = 7
+    out = torch.empty(T, D, dtype=dtype, device=DEV)
+    ops.embed_fwd(tok.to(DEV), table.to(DEV), out, V)
+    assert torch.equal(out.cpu(), table[tok])  # bit-exact row copies
+    dout = rnd(T, D, dtype=dtype, seed=10)
+    base = rnd(V, D, dtype=dtype, seed=11)
+    ref = base.float().index_add(0, tok, dout.float())
+    dt1 = base.to(DEV)
+    ops.embed_bwd(tok.to(DEV), dout.to(DEV), dt1, V)
+    torch.testing.assert_close(dt1.cpu().float(), ref, rtol=1e-5 if dtype == torch.float32 else 8e-3, atol=1e-4 if dtype == torch.float32 else 0.15)
+    dt2 = base.to(DEV)
+    ops.embed_bwd(tok.to(DEV), dout.to(DEV), dt2, V)
+    assert torch.equal(dt1, dt2), "scatter-add must be bitwise reproducible"
+    untouched = torch.ones(V, dtype=torch.bool)
+    untouched[tok] = False
+    assert torch.equal(dt1.cpu()[untouched], base[untouched])
+    # empty input is a no-op
+    ops.embed_bwd(torch.empty(0, dtype=torch.int64, device=DEV), torch.empty(0, D, dtype=dtype, device=DEV), dt2, V)
+    assert torch.equal(dt1, dt2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("vocab,ld", [(515, 520), (133_258, 133_376)])
+def test_cross_entropy_rows_reduce_and_grad(ops, dtype, vocab, ld):
+    rows = 24
+    logits = rnd(rows, ld, dtype=dtype, seed=12, scale=3.0)
+    g = torch.Generator().manual_seed(13)
+    labels = torch.randint(0, vocab, (rows,), generator=g)
+    labels[3] = -100
+    labels[rows - 1] = -100
+    labels[5] = vocab - 1
+    lr = logits[:, :vocab].float().clone().requires_grad_(True)
+    nll = F.cross_entropy(lr, labels, ignore_index=-100, reduction="none")
+    nll.sum().backward()
+    work = logits.to(DEV)
+    row_loss = torch.empty(rows, dtype=torch.float32, device=DEV)
+    row_lse = torch.empty(rows, dtype=torch.float32, device=DEV)
+    ops.ce_fwd(work, labels.to(DEV), vocab, -100, row_loss, row_lse, False)
+    assert torch.equal(work.cpu(), logits), "write_grad=False must leave the logits untouched"
+    torch.testing.assert_close(row_loss.cpu(), nll.detach(), rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(row_lse.cpu()[labels != -100], torch.logsumexp(lr.detach(), -1)[labels != -100], rtol=1e-6, atol=1e-5)
+    out = torch.empty(3, dtype=torch.float32, device=DEV)
+    ops.ce_reduce(row_loss, labels.to(DEV), -100, out)
+    n_valid = int((labels != -100).sum())
+    assert out.cpu()[2].item() == n_valid
+    assert out.cpu()[0].item() == pytest.approx(float(nll.sum()) / n_valid, rel=1e-5)
+    ops.ce_fwd(work, labels.to(DEV), vocab, -100, row_loss, None, True)
+    grad = work.cpu().float()
+    torch.testing.assert_close(grad[:, :vocab], lr.grad, rtol=1e-5 if dtype == torch.float32 else 1e-2, atol=1e-6 if dtype == torch.float32 else 4e-3)
+    assert (grad[:, vocab:] == 0).all() and (grad[3] == 0).all() and (grad[rows - 1] == 0).all()
+    # all rows ignored -> 0/0 = NaN like the reference
+    allign = torch.full((rows,), -100, dtype=torch.int64, device=DEV)
+    ops.ce_fwd(logits.to(DEV), allign, vocab, -100, row_loss, None, False)
+    ops.ce_reduce(row_loss, allign, -100, out)
+    assert math.isnan(out.cpu()[0].item()) and out.cpu()[2].item() == 0
+
+
+def test_count_tokens_matches_reference_counts(ops):
+    from oracle.step_oracle import count_token_types, token_type_ranges
+    from ssi.train_utils import count_token_types as ct_gpu, count_token_types_async
+    r = token_type_ranges(128000, 5000, True, 256)
+    g = torch.Generator().manual_seed(14)
+    tok = torch.randint(0, 133_258, (8, 2048), generator=g)
+    tok[:, -17:] = 133_006
+    lab = tok.clone()
+    lab[:, :25] = -100
+    ref = count_token_types(tok, r, 133_006)
+    assert ct_gpu(tok.to(DEV), r, 133_006) == ref  # bit-exact integers
+    dev = count_token_types_async(tok.to(DEV), r, 133_006, lab.to(DEV), -100).cpu().tolist()
+    assert dev[:4] == [ref[k] for k in r] and dev[4] == ref["total"] and dev[5] == int((lab != -100).sum())
+    empty = torch.empty(0, 4, dtype=torch.int64, device=DEV)
+    assert ct_gpu(empty, r, 0) == {"text": 0, "dsu": 0, "modality": 0, "special_text": 0, "total": 0}
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_adamw_scale_sumsq(ops, dtype):
+    n = 100_003  # odd tail
+    p0, g0 = rnd(n, seed=15), rnd(n, seed=16, scale=50.0)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_p], lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    p, m, v = p0.to(dtype).to(DEV), torch.zeros(n, dtype=dtype, device=DEV), torch.zeros(n, dtype=dtype, device=DEV)
+    gs = torch.tensor([1 / 50.0], dtype=torch.float32, device=DEV)
+    for step in range(1, 4):
+        gstep = g0 * (1 + 0.1 * step)
+        ref_p.grad = (gstep / 50.0).clone()
+        opt.step()
+        g = gstep.to(dtype).to(DEV)
+        ops.adamw_step(p, g, m, v, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=step, grad_scale_dev=gs, zero_grad=True)
+        assert (g == 0).all()
+    if dtype == torch.float32:
+        torch.testing.assert_close(p.cpu(), ref_p.detach(), rtol=0, atol=2e-6)
+        torch.testing.assert_close(m.cpu(), opt.state[ref_p]["exp_avg"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(v.cpu(), opt.state[ref_p]["exp_avg_sq"], rtol=1e-5, atol=1e-7)
+    else:
+        torch.testing.assert_close(p.cpu().float(), ref_p.detach(), rtol=0, atol=2e-2)
+    x = rnd(n, dtype=dtype, seed=17)
+    out = torch.empty(1, dtype=torch.float32, device=DEV)
+    ops.sumsq(x.to(DEV), out)
+    assert out.item() == pytest.approx(float(x.float().pow(2).sum()), rel=1e-5)
+    xs = x.to(DEV)
+    ops.scale_(xs, 0.5, torch.tensor([4.0], device=DEV))
+    torch.testing.assert_close(xs.cpu().float(), (x.float() * 2.0).to(dtype).float(), rtol=0, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _gemm_ref(layout, a, b):
+    a, b = a.double(), b.double()
+    return {0: a @ b.T, 1: a @ b, 2: a.T @ b}[layout]
+
+
+def _gemm_operands(layout, M, N, K, dtype, seed, integer=False):
+    g = torch.Generator().manual_seed(seed)
+    mk = (lambda *s: torch.randint(-3, 4, s, generator=g).float()) if integer else (lambda *s: torch.randn(*s, generator=g))
+    a = mk(M, K) if layout in (0, 1) else mk(K, M)
+    b = mk(N, K) if layout == 0 else mk(K, N)
+    return a.to(dtype), b.to(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (70, 130, 33), (256, 64, 512)])
+def test_gemm_generic(ops, dtype, layout, M, N, K):
+    from ssi import _lib
+    a, b = _gemm_operands(layout, M, N, K, dtype, 18)
+    prev = ops.set_impl(_lib.IMPL_GENERIC)
+    try:
+        c = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+        ops.gemm(layout, a.to(DEV), b.to(DEV), c)
+        ref = _gemm_ref(layout, a, b)
+        torch.testing.assert_close(c.cpu().double(), ref, rtol=1e-5 if dtype == torch.float32 else 1e-2, atol=1e-4 if dtype == torch.float32 else 0.02 * math.sqrt(K))
+        if dtype == torch.float32:
+            r = rnd(M, N, seed=19)
+            c0 = rnd(M, N, seed=20).to(DEV)
+            c1 = c0.clone()
+            ops.gemm(layout, a.to(DEV), b.to(DEV), c1, residual=r.to(DEV), alpha=0.5, alpha_dev=torch.tensor([4.0], device=DEV), accumulate=True)
+            torch.testing.assert_close(c1.cpu().double(), c0.cpu().double() + 2.0 * ref + r.double(), rtol=1e-5, atol=1e-4)
+    finally:
+        ops.set_impl(prev)
+
+
+@pytest.mark.parametrize("impl_name", ["IMPL_MFMA", "IMPL_MFMA_REGSTAGE"])
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 192), (1024, 256, 2048)])
+def test_gemm_mfma_bf16(ops, impl_name, layout, M, N, K):
+    from ssi import _lib
+    prev = ops.set_impl(getattr(_lib, impl_name))
+    try:
+        # (1) small-integer operands: every product and partial sum is exact in fp32 and representable in bf16 when
+        #     |sum| <= 256 — catches any row/column/k mapping error with asymmetric data
+        a, b = _gemm_operands(layout, M, N, min(K, 64), torch.bfloat16, 21, integer=True)
+        c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.gemm(layout, a.to(DEV), b.to(DEV), c)
+        ref = _gemm_ref(layout, a, b)
+        exact = ref.abs() <= 256
+        assert torch.equal(c.cpu().double()[exact], ref[exact]), "MFMA GEMM is not exact on small-integer operands"
+        # (2) random operands, full K, with alpha / residual / accumulate
+        a, b = _gemm_operands(layout, M, N, K, torch.bfloat16, 22)
+        r = rnd(M, N, dtype=torch.bfloat16, seed=23)
+        c0 = rnd(M, N, dtype=torch.bfloat16, seed=24)
+        c1 = c0.to(DEV)
+        ops.gemm(layout, a.to(DEV), b.to(DEV), c1, residual=r.to(DEV), alpha=0.5, alpha_dev=torch.tensor([2.0], device=DEV), accumulate=True)
+        ref = (_gemm_ref(layout, a, b).float().bfloat16().double() + c0.double()) + r.double()
+        torch.testing.assert_close(c1.cpu().double(), ref, rtol=2e-2, atol=0.03 * math.sqrt(K))
+        # (3) against the generic kernel on the same inputs (same rounding points): near-identical
+        c2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(layout, a.to(DEV), b.to(DEV), c2)
+        ops.set_impl(_lib.IMPL_GENERIC)
+        c3 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(layout, a.to(DEV), b.to(DEV), c3)
+        diff = (c2.float() - c3.float()).abs()
+        assert float(diff.max()) <= 2 ** -6 * float(c3.float().abs().max()) and float((diff > 0).float().mean()) < 0.2
+    finally:
+        ops.set_impl(prev)
+
+
+def test_gemm_mfma_forced_on_bad_shape_fails_loudly(ops):
+    from ssi import _lib
+    prev = ops.set_impl(_lib.IMPL_MFMA)
+    try:
+        a, b = _gemm_operands(0, 100, 256, 64, torch.bfloat16, 25)
+        with pytest.raises(RuntimeError):
+            ops.gemm(0, a.to(DEV), b.to(DEV), torch.empty(100, 256, dtype=torch.bfloat16, device=DEV))
+    finally:
+        ops.set_impl(prev)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _sdpa_ref(qkv, B, S, H, KV, hd):
+    q = qkv[:, : H * hd].view(B, S, H, hd).transpose(1, 2)
+    k = qkv[:, H * hd:(H + KV) * hd].view(B, S, KV, hd).transpose(1, 2).repeat_interleave(H // KV, dim=1)
+    v = qkv[:, (H + KV) * hd:].view(B, S, KV, hd).transpose(1, 2).repeat_interleave(H // KV, dim=1)
+    o = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+    return o.transpose(1, 2).reshape(B * S, H * hd)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,H,KV,hd", [(2, 45, 8, 2, 16), (2, 128, 4, 1, 64), (1, 200, 4, 4, 64)])
+def test_attention_generic_fwd_bwd(ops, dtype, B, S, H, KV, hd):
+    from ssi import _lib
+    prev = ops.set_impl(_lib.IMPL_GENERIC)
+    try:
+        qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=dtype, seed=26)
+        do = rnd(B * S, H * hd, dtype=dtype, seed=27)
+        qr = qkv.float().clone().requires_grad_(True)
+        oref = _sdpa_ref(qr, B, S, H, KV, hd)
+        oref.backward(do.float())
+        out = torch.empty(B * S, H * hd, dtype=dtype, device=DEV)
+        lse = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+        ops.attn_fwd(qkv.to(DEV), out, lse, B, S, H, KV, hd)
+        t = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(out.cpu().float(), oref.detach(), **t)
+        dqkv = torch.full_like(qkv, float("nan")).to(DEV)
+        delta = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+        ops.attn_bwd(qkv.to(DEV), out, do.to(DEV), lse, dqkv, delta, B, S, H, KV, hd)
+        t = dict(rtol=1e-3, atol=1e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=8e-2)
+        torch.testing.assert_close(dqkv.cpu().float(), qr.grad, **t)
+    finally:
+        ops.set_impl(prev)
