@@ -1,5 +1,492 @@
-// placeholder until the MFMA flash attention lands
+// Causal GQA flash attention on the gfx950 matrix cores (bf16, head_dim 64) — forward, dQ and dK/dV.
+// Replaces F.scaled_dot_product_attention(is_causal=True) inside torchtune's MultiHeadAttention and its autograd
+// (SURVEY.md §2.3 K5/K10).  qkv is the fused projection output [B*S, (H + 2 KV) * 64] after RoPE.
+//
+// Orientation (all three kernels): scores are produced TRANSPOSED or with the reduction index on the accumulator's ROW
+// axis, so that the 32x32 accumulator of one v_mfma_f32_32x32x16_bf16 is directly the B operand of the next product
+// (no LDS round trip, no lane shuffles for P):
+//   forward : S^T[key][q] = K Q^T      -> P^T -> O^T[d][q]  += V^T[d][key] P^T[key][q]      (row statistics per LANE)
+//   dQ      : S^T, dP^T[key][q] = V dO^T -> dS^T -> dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+//   dK/dV   : S[q][key] = Q K^T, dP[q][key] = dO V^T -> P, dS -> dV^T[d][key] += dO^T[d][q] P[q][key],
+//             dK^T[d][key] += Q^T[d][q] dS[q][key]                                          (key on the lane, sums in regs)
+// k-contiguous operands come from LDS by ds_read_b128, k-strided ones by ds_read_b64_tr_b16 (hardware transpose); tiles
+// are [rows][64] bf16 (128-B rows) with a 16-B-chunk XOR swizzle chosen per tile for the way it is read.
+// Workgroup = 4 waves; the waves of a workgroup share one kv head (K/V tiles staged once for the 4 query heads of a GQA
+// group).  No atomics anywhere: dQ gets its own pass (recomputing S and dP) so every output has exactly one writer and
+// results are bitwise reproducible.
 #include "common.cuh"
-bool ssi_attn_mfma_supported(int64_t, int64_t, int64_t, int, int, int, int) { return false; }
-int ssi_attn_fwd_mfma(const void*, int64_t, void*, float*, int64_t, int64_t, int, int, void*) { return SSI_ERR_UNSUPPORTED; }
-int ssi_attn_bwd_mfma(const void*, int64_t, const void*, const void*, const float*, void*, float*, int64_t, int64_t, int, int, void*) { return SSI_ERR_UNSUPPORTED; }
+
+namespace {
+
+constexpr int HD = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+enum { SWZ_ROW = 0, SWZ_TR = 1 };
+template <int SWZ> __device__ __forceinline__ int swz(int row) {
+    return SWZ == SWZ_ROW ? ((row >> 1) & 7) : (((row >> 1) & 1) << 2);
+}
+
+// 32 rows x 16 k fragment of a [rows][64] tile: lane l holds row = row_base + (l & 31), k = 16 ks + 8 (l >> 5) + j
+template <int SWZ> __device__ __forceinline__ bf16x8 frag_row(const char* tile, int row_base, int ks, int lane) {
+    const int row = row_base + (lane & 31);
+    const int chunk = (2 * ks + (lane >> 5)) ^ swz<SWZ>(row);
+    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + chunk * 16);
+}
+
+// transposed fragment: lane l holds column c = cbase + (l & 31) of tile rows kbase + {8 (j >> 2) + 4 (l >> 5) + (j & 3)}, j = 0..7
+// (the k order in which a 32x32 accumulator, converted to bf16, presents itself as an MFMA operand)
+template <int SWZ> __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int kbase, int cbase, int lane) {
+    const int G = lane >> 4, h = G >> 1, i = lane & 15, q = i >> 2, p = i & 3;
+    const int chunk = ((cbase + 16 * (G & 1)) >> 3) + (p >> 1);
+    const int r0 = kbase + 4 * h + q, r1 = r0 + 8;
+    const char* a0 = tile + r0 * 128 + ((chunk ^ swz<SWZ>(r0)) * 16) + 8 * (p & 1);
+    const char* a1 = tile + r1 * 128 + ((chunk ^ swz<SWZ>(r1)) * 16) + 8 * (p & 1);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// registers 8 s .. 8 s + 7 of a 32x32 accumulator as a bf16 operand fragment (k-step s)
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (bf16_t)a[8 * s + j];
+    return f;
+}
+
+__device__ __forceinline__ bf16x8 scale_frag(bf16x8 v, float s) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)((float)v[j] * s);
+    return v;
+}
+
+// stage a [ROWS][64] bf16 tile global -> registers -> LDS (swizzled), split so the loads fly under compute (T14)
+template <int ROWS, int NTHR> struct TileStage {
+    static constexpr int N = ROWS * 8 / NTHR;  // 16-B chunks per thread
+    u32x4 r[N];
+    __device__ __forceinline__ void load(const bf16_t* g, int64_t ld, int tid) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int c = tid + i * NTHR;
+            r[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)(c >> 3) * ld + (c & 7) * 8);
+        }
+    }
+    template <int SWZ> __device__ __forceinline__ void store(char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int c = tid + i * NTHR, row = c >> 3, chunk = (c & 7) ^ swz<SWZ>(row);
+            *reinterpret_cast<u32x4*>(tile + row * 128 + chunk * 16) = r[i];
+        }
+    }
+};
+
+// =====================================================================================================================
+// forward
+// =====================================================================================================================
+// grid.x = B * KV * (S / (32 * QPW)),  QPW = 4 / rep q-blocks per workgroup; wave w: head kvh*rep + w % rep, q-block w / rep
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t ld, bf16_t* __restrict__ out,
+                                                       float* __restrict__ lse, int S, int H, int KV) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];  // [buf][K|V][64][64] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rep = H / KV, qpw = 4 / rep;
+    const int nqb = S / (32 * qpw);
+    // heavy q-blocks first
+    const int qgrp = nqb - 1 - (int)(blockIdx.x % nqb);
+    const int kvh = (int)(blockIdx.x / nqb) % KV;
+    const int b = (int)(blockIdx.x / nqb) / KV;
+    const int head = kvh * rep + wave % rep;
+    const int q0 = (qgrp * qpw + wave / rep) * 32;
+    const int q_last_wg = (qgrp * qpw + qpw - 1) * 32 + 31;
+    const int nt = q_last_wg / 64 + 1;
+    const int h = lane >> 5;
+    const int64_t row0 = (int64_t)b * S;
+    const bf16_t* kbase = qkv + row0 * ld + (int64_t)H * HD + (int64_t)kvh * HD;
+    const bf16_t* vbase = kbase + (int64_t)KV * HD;
+
+    // Q as the B operand of S^T = K Q^T, pre-scaled by 1/sqrt(64) = 2^-3 (exact in bf16)
+    bf16x8 qf[4];
+    {
+        const bf16_t* qrow = qkv + (row0 + q0 + (lane & 31)) * ld + (int64_t)head * HD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = scale_frag(*reinterpret_cast<const bf16x8*>(qrow + 16 * ks), 0.125f);
+    }
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m = -INFINITY, lsum = 0.f;  // running max (scaled-score units) and this half-wave's partial row sum
+    const int qg = q0 + (lane & 31);
+
+    TileStage<64, 256> sk, sv;
+    sk.load(kbase, ld, tid);
+    sv.load(vbase, ld, tid);
+    sk.store<SWZ_ROW>(smem, tid);
+    sv.store<SWZ_TR>(smem + 8192, tid);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const char* kt = smem + (t & 1) * 16384;
+        const char* vt = kt + 8192;
+        if (t + 1 < nt) {
+            sk.load(kbase + (int64_t)(t + 1) * 64 * ld, ld, tid);
+            sv.load(vbase + (int64_t)(t + 1) * 64 * ld, ld, tid);
+        }
+        const int k0 = t * 64;
+        if (k0 <= q0 + 31) {  // wave-uniform: this tile intersects the causal range of the wave's rows
+            f32x16 sacc[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(kt, kb * 32, ks, lane), qf[ks], sacc[kb], 0, 0, 0);
+            }
+            if (k0 + 63 > q0) {  // diagonal tile: mask keys beyond the query
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (k0 + kb * 32 + rowmap(r, h) > qg) sacc[kb][r] = -INFINITY;
+            }
+            float mx = sacc[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
+            const float mb = mn * LOG2E;
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[kb][r] * LOG2E - mb);
+                    sacc[kb][r] = p;
+                    rs += p;
+                }
+            lsum = lsum * alpha + rs;
+            m = mn;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 pf = acc_frag(sacc[s >> 1], s & 1);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_TR>(vt, s * 16, db * 32, lane), pf, oacc[db], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nt) {
+            char* nk = smem + ((t + 1) & 1) * 16384;
+            sk.store<SWZ_ROW>(nk, tid);
+            sv.store<SWZ_TR>(nk + 8192, tid);
+        }
+        __syncthreads();
+    }
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.f / ltot;
+    bf16_t* orow = out + (row0 + qg) * ((int64_t)H * HD) + (int64_t)head * HD;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(oacc[db][4 * g + e] * inv);
+            *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * g + 4 * h) = v;
+        }
+    if (h == 0) lse[((int64_t)b * H + head) * S + qg] = m + logf(ltot);
+}
+
+// =====================================================================================================================
+// backward: delta = rowsum(dO * O)
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, int64_t rows, int S, int H) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (row, head, 8-element chunk)
+    const int64_t rh = g >> 3;
+    if (rh >= rows * H) return;
+    const int64_t row = rh / H;
+    const int head = (int)(rh % H);
+    const int64_t off = rh * HD + (g & 7) * 8;
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(out + off), c = *reinterpret_cast<const bf16x8*>(dout + off);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)c[j];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if ((g & 7) == 0) delta[((row / S) * H + head) * S + (row % S)] = s;
+}
+
+// =====================================================================================================================
+// backward: dQ   (same decomposition as the forward)
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S,
+                                                          int H, int KV) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rep = H / KV, qpw = 4 / rep;
+    const int nqb = S / (32 * qpw);
+    const int qgrp = nqb - 1 - (int)(blockIdx.x % nqb);
+    const int kvh = (int)(blockIdx.x / nqb) % KV;
+    const int b = (int)(blockIdx.x / nqb) / KV;
+    const int head = kvh * rep + wave % rep;
+    const int q0 = (qgrp * qpw + wave / rep) * 32;
+    const int nt = ((qgrp * qpw + qpw - 1) * 32 + 31) / 64 + 1;
+    const int h = lane >> 5;
+    const int64_t row0 = (int64_t)b * S;
+    const bf16_t* kbase = qkv + row0 * ld + (int64_t)H * HD + (int64_t)kvh * HD;
+    const bf16_t* vbase = kbase + (int64_t)KV * HD;
+    const int qg = q0 + (lane & 31);
+
+    bf16x8 qf[4], dof[4];
+    {
+        const bf16_t* qrow = qkv + (row0 + qg) * ld + (int64_t)head * HD + 8 * h;
+        const bf16_t* drow = dout + (row0 + qg) * ((int64_t)H * HD) + (int64_t)head * HD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = scale_frag(*reinterpret_cast<const bf16x8*>(qrow + 16 * ks), 0.125f);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(drow + 16 * ks);
+        }
+    }
+    const float lb = lse[((int64_t)b * H + head) * S + qg] * LOG2E;
+    const float dl = delta[((int64_t)b * H + head) * S + qg];
+    f32x16 dq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+
+    TileStage<64, 256> sk, sv;
+    sk.load(kbase, ld, tid);
+    sv.load(vbase, ld, tid);
+    sk.store<SWZ_ROW>(smem, tid);
+    sv.store<SWZ_ROW>(smem + 8192, tid);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const char* kt = smem + (t & 1) * 16384;
+        const char* vt = kt + 8192;
+        if (t + 1 < nt) {
+            sk.load(kbase + (int64_t)(t + 1) * 64 * ld, ld, tid);
+            sv.load(vbase + (int64_t)(t + 1) * 64 * ld, ld, tid);
+        }
+        const int k0 = t * 64;
+        if (k0 <= q0 + 31) {
+            f32x16 sacc[2], pacc[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sacc[kb][r] = 0.f; pacc[kb][r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(kt, kb * 32, ks, lane), qf[ks], sacc[kb], 0, 0, 0);
+                    pacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(vt, kb * 32, ks, lane), dof[ks], pacc[kb], 0, 0, 0);
+                }
+            }
+            const bool diag = k0 + 63 > q0;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float p = __builtin_amdgcn_exp2f(sacc[kb][r] * LOG2E - lb);
+                    if (diag && k0 + kb * 32 + rowmap(r, h) > qg) p = 0.f;
+                    sacc[kb][r] = p * (pacc[kb][r] - dl);  // dS^T (the 1/sqrt(d) factor is applied once at the end)
+                }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 dsf = acc_frag(sacc[s >> 1], s & 1);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(kt, s * 16, db * 32, lane), dsf, dq[db], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nt) {
+            char* nk = smem + ((t + 1) & 1) * 16384;
+            sk.store<SWZ_ROW>(nk, tid);
+            sv.store<SWZ_ROW>(nk + 8192, tid);
+        }
+        __syncthreads();
+    }
+    bf16_t* drow = dqkv + (row0 + qg) * ld + (int64_t)head * HD;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(dq[db][4 * g + e] * 0.125f);
+            *reinterpret_cast<bf16x4*>(drow + db * 32 + 8 * g + 4 * h) = v;
+        }
+}
+
+// =====================================================================================================================
+// backward: dK, dV.  Workgroup = (b, kv head, 32-key block); its 4 waves split (query head of the group, q-block
+// stripe); each keeps dK^T and dV^T of the 32 keys in accumulators over its sweep; one LDS reduction at the end.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                           const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S,
+                                                           int H, int KV) {
+    // per wave: Q tile [32][64] + dO tile [32][64] (4 KiB each); reused at the end as [4 waves][2][64 d][32 keys] fp32
+    __shared__ __attribute__((aligned(16))) char smem[4 * 2 * 64 * 32 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rep = H / KV, stripes = 4 / rep;
+    const int nkb = S / 32;
+    const int kblk = (int)(blockIdx.x % nkb);  // low key blocks (most work) are dispatched first
+    const int kvh = (int)(blockIdx.x / nkb) % KV;
+    const int b = (int)(blockIdx.x / nkb) / KV;
+    const int head = kvh * rep + wave % rep;
+    const int stripe = wave / rep;
+    const int h = lane >> 5;
+    const int64_t row0 = (int64_t)b * S;
+    const int key0 = kblk * 32;
+    const int kg = key0 + (lane & 31);
+    char* qt = smem + wave * 8192;
+    char* dt = qt + 4096;
+
+    // K (pre-scaled by 2^-3) and V as B operands: lane holds row key0 + (l & 31), d = 16 ks + 8 h + j
+    bf16x8 kf[4], vf[4];
+    {
+        const bf16_t* krow = qkv + (row0 + kg) * ld + (int64_t)H * HD + (int64_t)kvh * HD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = scale_frag(*reinterpret_cast<const bf16x8*>(krow + 16 * ks), 0.125f);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(krow + (int64_t)KV * HD + 16 * ks);
+        }
+    }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+    const int nq_total = nkb - kblk;                       // q-blocks kblk .. nkb-1
+    const int trips = (nq_total + stripes - 1) / stripes;  // uniform trip count for the barriers
+    TileStage<32, 64> sq, sd;
+    for (int it = 0; it < trips; ++it) {
+        const int qb = kblk + it * stripes + stripe;
+        const bool active = qb < nkb;  // wave-uniform
+        const int q0 = qb * 32;
+        if (active) {
+            sq.load(qkv + (row0 + q0) * ld + (int64_t)head * HD, ld, lane);
+            sd.load(dout + (row0 + q0) * ((int64_t)H * HD) + (int64_t)head * HD, (int64_t)H * HD, lane);
+            sq.store<SWZ_ROW>(qt, lane);
+            sd.store<SWZ_ROW>(dt, lane);
+        }
+        __syncthreads();
+        if (active) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(qt, 0, ks, lane), kf[ks], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(dt, 0, ks, lane), vf[ks], pacc, 0, 0, 0);
+            }
+            // rows of the accumulators are queries q0 + rowmap(r, h); row constants come in runs of 4
+            const float* lrow = lse + ((int64_t)b * H + head) * S + q0 + 4 * h;
+            const float* drow = delta + ((int64_t)b * H + head) * S + q0 + 4 * h;
+            const bool diag = q0 < key0 + 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lrow + 8 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(drow + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    float p = __builtin_amdgcn_exp2f(sacc[r] * LOG2E - l4[e] * LOG2E);
+                    if (diag && kg > q0 + rowmap(r, h)) p = 0.f;
+                    sacc[r] = p;
+                    pacc[r] = p * (pacc[r] - d4[e]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = acc_frag(sacc, s), dsf = acc_frag(pacc, s);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(dt, s * 16, db * 32, lane), pf, dv[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(qt, s * 16, db * 32, lane), dsf, dk[db], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // cross-wave reduction: smem as float [wave][2][64 d][32 keys]
+    float* red = reinterpret_cast<float*>(smem) + wave * (2 * 64 * 32);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = db * 32 + rowmap(r, h);
+            red[d * 32 + (lane & 31)] = dk[db][r] * 0.125f;
+            red[64 * 32 + d * 32 + (lane & 31)] = dv[db][r];
+        }
+    __syncthreads();
+    // thread -> (which, key, 8-d chunk): 2 * 32 * 8 = 512 items over 256 threads
+    const float* all = reinterpret_cast<const float*>(smem);
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        const int item = tid + rnd * 256;
+        const int which = item >> 8, key = (item >> 3) & 31, dc = item & 7;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = which * 64 * 32 + (dc * 8 + e) * 32 + key;
+            o[e] = (bf16_t)(all[idx] + all[idx + 2 * 64 * 32] + all[idx + 4 * 64 * 32] + all[idx + 6 * 64 * 32]);
+        }
+        bf16_t* dst = dqkv + (row0 + key0 + key) * ld + (int64_t)H * HD + (int64_t)(which ? KV : 0) * HD + (int64_t)kvh * HD + dc * 8;
+        *reinterpret_cast<bf16x8*>(dst) = o;
+    }
+}
+
+}  // namespace
+
+bool ssi_attn_mfma_supported(int64_t ld, int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype) {
+    if (dtype != SSI_BF16 || head_dim != HD) return false;
+    const int rep = n_heads / n_kv;
+    if (rep != 1 && rep != 2 && rep != 4) return false;
+    if (seq < 128 || seq % 128 != 0) return false;  // q-block group of up to 128 rows, 64-key tiles
+    if (ld % 8 != 0 || batch <= 0) return false;
+    if (batch * n_kv * (seq / 32) > (1LL << 30)) return false;
+    return true;
+}
+
+int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, int64_t batch, int64_t seq, int n_heads, int n_kv,
+                      void* stream) {
+    const int rep = n_heads / n_kv, qpw = 4 / rep;
+    const unsigned grid = (unsigned)(batch * n_kv * (seq / (32 * qpw)));
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)out, lse,
+                       (int)seq, n_heads, n_kv);
+    SSI_LAUNCH_CHECK();
+    return SSI_OK;
+}
+
+int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
+                      int64_t batch, int64_t seq, int n_heads, int n_kv, void* stream) {
+    auto st = (hipStream_t)stream;
+    const int rep = n_heads / n_kv, qpw = 4 / rep;
+    const int64_t rows = batch * seq;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)ssi_cdiv(rows * n_heads * 8, 256)), dim3(256), 0, st, (const bf16_t*)out,
+                       (const bf16_t*)dout, delta, rows, (int)seq, n_heads);
+    SSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * n_kv * (seq / (32 * qpw)))), dim3(256), 0, st, (const bf16_t*)qkv,
+                       ld, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, (int)seq, n_heads, n_kv);
+    SSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(batch * n_kv * (seq / 32))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
+                       (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, (int)seq, n_heads, n_kv);
+    SSI_LAUNCH_CHECK();
+    return SSI_OK;
+}

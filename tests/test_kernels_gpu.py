@@ -332,3 +332,52 @@ def test_attention_generic_fwd_bwd(ops, dtype, B, S, H, KV, hd):
         torch.testing.assert_close(dqkv.cpu().float(), qr.grad, **t)
     finally:
         ops.set_impl(prev)
+
+
+@pytest.mark.parametrize("B,S,H,KV", [(2, 128, 4, 1), (1, 256, 4, 2), (2, 384, 2, 2), (1, 2048, 8, 2)])
+def test_attention_mfma_fwd_bwd(ops, B, S, H, KV):
+    """MFMA flash attention (bf16, head_dim 64) vs torch SDPA in fp32 on the same bf16 inputs, and vs the generic HIP
+    kernel.  Includes a spiked key (forces the online-softmax rescale on a late tile) and a large-magnitude query."""
+    from ssi import _lib
+    hd = 64
+    qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=28)
+    qkv[S // 2 + 3, H * hd: H * hd + hd] *= 6.0      # one key row of kv head 0 stands out for later queries
+    qkv[S - 5, :hd] *= 4.0                            # one query row with large scores
+    do = rnd(B * S, H * hd, dtype=torch.bfloat16, seed=29)
+    qr = qkv.float().clone().requires_grad_(True)
+    oref = _sdpa_ref(qr, B, S, H, KV, hd)
+    oref.backward(do.float())
+    outs = {}
+    for impl in (_lib.IMPL_MFMA, _lib.IMPL_GENERIC):
+        prev = ops.set_impl(impl)
+        try:
+            out = torch.full((B * S, H * hd), float("nan"), dtype=torch.bfloat16, device=DEV)
+            lse = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+            ops.attn_fwd(qkv.to(DEV), out, lse, B, S, H, KV, hd)
+            dqkv = torch.full_like(qkv, float("nan")).to(DEV)
+            delta = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+            ops.attn_bwd(qkv.to(DEV), out, do.to(DEV), lse, dqkv, delta, B, S, H, KV, hd)
+            outs[impl] = (out.cpu().float(), lse.cpu(), dqkv.cpu().float())
+        finally:
+            ops.set_impl(prev)
+    out, lse, dqkv = outs[_lib.IMPL_MFMA]
+    assert torch.isfinite(out).all() and torch.isfinite(dqkv).all()
+    torch.testing.assert_close(out, oref.detach(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(lse, outs[_lib.IMPL_GENERIC][1], rtol=1e-4, atol=2e-3)
+    # gradients: relative to the tensor's scale (bf16 P/dS operands)
+    scale = float(qr.grad.abs().max())
+    err = float((dqkv - qr.grad).abs().max())
+    assert err <= 3e-2 * scale, f"dqkv max error {err} vs scale {scale}"
+    rel_fro = float((dqkv - qr.grad).norm() / qr.grad.norm())
+    assert rel_fro <= 1.5e-2, rel_fro
+    # bitwise reproducible (no atomics)
+    prev = ops.set_impl(_lib.IMPL_MFMA)
+    try:
+        out2 = torch.empty(B * S, H * hd, dtype=torch.bfloat16, device=DEV)
+        lse2 = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+        ops.attn_fwd(qkv.to(DEV), out2, lse2, B, S, H, KV, hd)
+        d2 = torch.empty_like(qkv).to(DEV)
+        ops.attn_bwd(qkv.to(DEV), out2, do.to(DEV), lse2, d2, torch.empty(B * H * S, dtype=torch.float32, device=DEV), B, S, H, KV, hd)
+        assert torch.equal(out2.cpu().float(), out) and torch.equal(d2.cpu().float(), dqkv)
+    finally:
+        ops.set_impl(prev)
