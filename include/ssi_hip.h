@@ -95,6 +95,13 @@ int ssi_gemm(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t
              void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev, int accumulate, int dtype,
              void* stream);
 
+/* Split-K variant for long-K / small-output contractions (weight gradients): `splits` K-slices into fp32 slabs in
+ * `workspace` (ssi_gemm_splitk_workspace_bytes), then one reduction pass with the same epilogue as ssi_gemm. */
+int64_t ssi_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int splits);
+int ssi_gemm_splitk(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                    void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev, int accumulate, int dtype,
+                    int splits, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- K9  CEWithChunkedOutputLoss (ssi/trainer.py:300; F.cross_entropy(logits.float(), reduction="sum")) -------------- */
 /* logits: [rows, ld] (columns [0, vocab) are real, [vocab, ld) padding).  labels: already shifted (ssi/loss.py:16).
  * row_loss[r] = lse(logits[r]) - logits[r, label] (0 if ignored).  If write_grad: logits[r, :] is OVERWRITTEN by

@@ -9,6 +9,10 @@ int ssi_gemm_mfma_bf16(int layout, int64_t M, int64_t N, int64_t K, const void* 
 bool ssi_gemm_mfma_supported(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                              int64_t ldb, const void* C, int64_t ldc, const void* R);
 
+int ssi_gemm_mfma_bf16_splitk(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                              int64_t ldb, void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev,
+                              int accumulate, int splits, float* slabs, void* stream);
+
 static int g_impl = SSI_IMPL_AUTO;
 extern "C" int ssi_set_impl(int impl) {
     const int prev = g_impl;
@@ -111,4 +115,25 @@ extern "C" int ssi_gemm(int layout, int64_t M, int64_t N, int64_t K, const void*
                                                  alpha, alpha_dev, accumulate));
     SSI_LAUNCH_CHECK();
     return SSI_OK;
+}
+
+// Split-K form of ssi_gemm for contractions whose output grid cannot fill 256 CUs (weight gradients of the square
+// projections: K = tokens is long, M x N is small).  The K range is cut into `splits` slices computed by separate
+// workgroups into fp32 slabs ([splits, M, N] in `workspace`), then one pass sums the slabs and applies the epilogue.
+// MFMA path only (same shape rules as ssi_gemm); splits == 1 forwards to ssi_gemm.
+extern "C" int64_t ssi_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int splits) {
+    return splits <= 1 ? 0 : (int64_t)splits * M * N * (int64_t)sizeof(float);
+}
+
+extern "C" int ssi_gemm_splitk(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                               int64_t ldb, void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev,
+                               int accumulate, int dtype, int splits, void* workspace, int64_t workspace_bytes, void* stream) {
+    const bool mfma_ok = dtype == SSI_BF16 && ssi_gemm_mfma_supported(layout, M, N, K, A, lda, B, ldb, C, ldc, R);
+    if (splits <= 1 || !mfma_ok || g_impl == SSI_IMPL_GENERIC || K / 64 < splits)
+        return ssi_gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, accumulate, dtype, stream);
+    SSI_CHECK_ARG(layout == SSI_GEMM_NT || layout == SSI_GEMM_NN || layout == SSI_GEMM_TN);
+    SSI_CHECK_ARG(splits <= 64 && ((uintptr_t)workspace % 16) == 0);
+    if (!workspace || workspace_bytes < ssi_gemm_splitk_workspace_bytes(M, N, splits)) { ssi_set_error("ssi_gemm_splitk: workspace too small"); return SSI_ERR_WORKSPACE; }
+    return ssi_gemm_mfma_bf16_splitk(layout, M, N, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, accumulate, splits,
+                                     (float*)workspace, stream);
 }

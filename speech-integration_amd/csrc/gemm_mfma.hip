@@ -4,8 +4,8 @@
 // Tile: 256 x 256 x 64 per 512-thread workgroup (8 waves as 2(M) x 4(N), 128 x 64 outputs per wave,
 //       32 accumulator tiles of v_mfma_f32_16x16x32_bf16 = 128 accumulator VGPRs per lane).
 // LDS : 2 buffers x (A 32 KiB + B 32 KiB) = 128 KiB for the K pipeline, reused (144 KiB total) by the epilogue.
-// HBM -> LDS: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip), tile t+1 in flight under the MFMAs of tile t,
-//       one barrier per K-tile.  LDS images are lane-linear; the bank swizzle is applied on the per-lane SOURCE address
+// HBM -> LDS: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip), tile t+2 issued as soon as tile t has been read,
+//       one barrier per K-tile; inside a tile every block of 16 MFMAs overlaps the ds_reads of the next block.  LDS images are lane-linear; the bank swizzle is applied on the per-lane SOURCE address
 //       and again on the read address (same involution both sides).
 // Operand forms (all three layouts of ssi_gemm use the same main loop):
 //   ROW  tile [rows][64 k]  (k contiguous in memory): fragments by ds_read_b128, 16-B chunk c of row r stored at
@@ -41,9 +41,9 @@ __device__ __forceinline__ int col_swz(int krow) { return ((krow & 3) | (((krow 
 
 // ---- HBM -> LDS staging of one operand tile ------------------------------------------------------------------------
 // ROW: rows r0..r0+255 of a [*, ld] matrix, k columns k0..k0+63.  COL: k-rows k0..k0+63, columns c0..c0+255.
-template <bool COL, bool GLDS>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, int64_t r0, int64_t k0,
-                                           char* lds_tile, int tid, u32x4 (&regs)[4]) {
+template <bool COL>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, int64_t r0, int64_t k0, char* lds_tile,
+                                           int tid) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const bf16_t* src;
@@ -56,18 +56,10 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t
             const int chunk = (tid & 31) ^ col_swz(krow);
             src = g + (k0 + krow) * ld + r0 + chunk * 8;
         }
-        if (GLDS) {
-            // wave-uniform LDS base; hardware adds lane*16
-            const int wave_base = __builtin_amdgcn_readfirstlane(p * 8192 + (tid >> 6) * 1024);
-            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_tile + wave_base), 16, 0, 0);
-        } else {
-            regs[p] = *reinterpret_cast<const u32x4*>(src);
-        }
+        // wave-uniform LDS base; the hardware adds lane * 16
+        const int wave_base = __builtin_amdgcn_readfirstlane(p * 8192 + (tid >> 6) * 1024);
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_tile + wave_base), 16, 0, 0);
     }
-}
-__device__ __forceinline__ void write_staged(char* lds_tile, int tid, const u32x4 (&regs)[4]) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(lds_tile + p * 8192 + tid * 16) = regs[p];
 }
 
 // ---- LDS -> MFMA fragment --------------------------------------------------------------------------------------------
@@ -108,13 +100,16 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
     tn = in_group / gm;
 }
 
-template <bool A_COL, bool B_COL, bool GLDS>
+// SPLITK: blockIdx.y selects a contiguous range of K-tiles; the fp32 partial tile goes to slab[blockIdx.y] (an [M, N] fp32
+// matrix in the workspace) and splitk_reduce_kernel applies alpha / accumulate / residual and the bf16 rounding.
+template <bool A_COL, bool B_COL, bool SPLITK>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int tiles_n, int64_t K,
                                                                const bf16_t* __restrict__ A, int64_t lda,
                                                                const bf16_t* __restrict__ B, int64_t ldb,
                                                                bf16_t* __restrict__ C, int64_t ldc,
                                                                const bf16_t* __restrict__ R, float alpha,
-                                                               const float* __restrict__ alpha_dev, int accumulate) {
+                                                               const float* __restrict__ alpha_dev, int accumulate,
+                                                               float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,43 +124,81 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (int)(K / BK);
-    u32x4 ra[4], rb[4];
+    const int nk_total = (int)(K / BK);
+    const int kt_begin = SPLITK ? (int)((int64_t)blockIdx.y * nk_total / gridDim.y) : 0;
+    const int kt_end = SPLITK ? (int)((int64_t)(blockIdx.y + 1) * nk_total / gridDim.y) : nk_total;
+    const int nk = kt_end - kt_begin;
+    const int64_t kofs = (int64_t)kt_begin * BK;
     auto tileA = [&](int buf) { return smem + buf * 2 * TILE_BYTES; };
     auto tileB = [&](int buf) { return smem + buf * 2 * TILE_BYTES + TILE_BYTES; };
+    auto stage = [&](int kt, int buf) {
+        stage_tile<A_COL>(A, lda, m0, kofs + (int64_t)kt * BK, tileA(buf), tid);
+        stage_tile<B_COL>(B, ldb, n0, kofs + (int64_t)kt * BK, tileB(buf), tid);
+    };
+    // Fragment registers: the wave's 128 x 64 tile is walked as 2 row halves (4 m-tiles each) x 2 k-halves per K-tile.
+    // a0/a1 alternate between the row halves, b0/b1 between the k-halves, so every block of 16 MFMAs runs while the
+    // ds_reads of the NEXT block are in flight (the two waves of a SIMD then interleave MFMA and LDS work instead of
+    // colliding on each in lockstep).
+    bf16x8 a0[4], a1[4], b0[4], b1[4];
+    auto readA = [&](bf16x8 (&dst)[4], const char* la, int half, int kh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = read_frag<A_COL>(la, wm * WM + (half * 4 + i) * 16, kh, lane);
+    };
+    auto readB = [&](bf16x8 (&dst)[4], const char* lb, int kh) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = read_frag<B_COL>(lb, wn * WN + j * 16, kh, lane);
+    };
+    auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[4], int half) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j][half * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][half * 4 + i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
 
-    stage_tile<A_COL, GLDS>(A, lda, m0, 0, tileA(0), tid, ra);
-    stage_tile<B_COL, GLDS>(B, ldb, n0, 0, tileB(0), tid, rb);
-    if (!GLDS) { write_staged(tileA(0), tid, ra); write_staged(tileB(0), tid, rb); }
-
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // both tiles landed
+    readA(a0, tileA(0), 0, 0);
+    readB(b0, tileB(0), 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        __syncthreads();  // tile kt landed (vmcnt(0) + barrier); every wave is done reading buffer cur^1
-        if (kt + 1 < nk) {
-            stage_tile<A_COL, GLDS>(A, lda, m0, (int64_t)(kt + 1) * BK, tileA(cur ^ 1), tid, ra);
-            stage_tile<B_COL, GLDS>(B, ldb, n0, (int64_t)(kt + 1) * BK, tileB(cur ^ 1), tid, rb);
-        }
         const char* la = tileA(cur);
         const char* lb = tileB(cur);
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            bf16x8 bfr[NT], afr[MT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bfr[j] = read_frag<B_COL>(lb, wn * WN + j * 16, kh, lane);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) afr[i] = read_frag<A_COL>(la, wm * WM + i * 16, kh, lane);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], afr[i], acc[j][i], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+        readA(a1, la, 1, 0);
+        mma(a0, b0, 0);
+        readA(a0, la, 0, 1);
+        readB(b1, lb, 1);
+        mma(a1, b0, 1);
+        readA(a1, la, 1, 1);
+        mma(a0, b1, 0);
+        if (kt + 1 < nk) {
+            // hipcc does not reliably order LDS-DMA against later ds_reads of another buffer: wait explicitly
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // every wave has read all of tile kt; tile kt+1 has landed
+            if (kt + 2 < nk) stage(kt + 2, cur);
+            readA(a0, tileA(cur ^ 1), 0, 0);
+            readB(b0, tileB(cur ^ 1), 0);
         }
-        if (!GLDS && kt + 1 < nk) { write_staged(tileA(cur ^ 1), tid, ra); write_staged(tileB(cur ^ 1), tid, rb); }
+        mma(a1, b1, 1);
     }
 
     // ---- epilogue: acc[j][i] holds C[m = wm*128 + i*16 + (lane&15)][n = wn*64 + j*16 + (lane>>4)*4 + r] ----------------
+    if (SPLITK) {  // fp32 partials, 4 consecutive columns per lane (64-B row segments per 16-lane group)
+        float* slab = slabs + (int64_t)blockIdx.y * ((int64_t)tiles_m * BM) * ((int64_t)tiles_n * BN);
+        const int64_t ldn = (int64_t)tiles_n * BN;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int64_t row = m0 + wm * WM + i * 16 + (lane & 15), col = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<f32x4*>(slab + row * ldn + col) = acc[j][i];
+            }
+        return;
+    }
     __syncthreads();
     const float al = alpha * (alpha_dev ? *alpha_dev : 1.f);
     char* ep = smem + wave * EPI_WAVE_BYTES;
@@ -206,24 +239,72 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
     }
 }
 
-template <bool A_COL, bool B_COL, bool GLDS>
+// C = (accumulate ? C : 0) + bf16(alpha * sum_s slab[s]) (+ R): one 16-B store per thread, same rounding points as the
+// direct epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, int64_t M, int64_t N,
+                                                            bf16_t* __restrict__ C, int64_t ldc, const bf16_t* __restrict__ R,
+                                                            float alpha, const float* __restrict__ alpha_dev, int accumulate) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nvec = M * N / 8;
+    if (v >= nvec) return;
+    const float al = alpha * (alpha_dev ? *alpha_dev : 1.f);
+    const int64_t row = (v * 8) / N, col = (v * 8) % N;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    for (int s = 0; s < splits; ++s) {
+        const float* p = slabs + (int64_t)s * M * N + row * N + col;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[e] += a[e]; f[4 + e] += b[e]; }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(f[e] * al);
+    const int64_t off = row * ldc + col;
+    if (accumulate || R) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (float)o[e];
+        if (accumulate) {
+            const bf16x8 c = *reinterpret_cast<const bf16x8*>(C + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += (float)c[e];
+        }
+        if (R) {
+            const bf16x8 c = *reinterpret_cast<const bf16x8*>(R + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += (float)c[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)f[e];
+    }
+    *reinterpret_cast<bf16x8*>(C + off) = o;
+}
+
+template <bool A_COL, bool B_COL, bool SPLITK>
 int launch(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
-           int64_t ldc, const void* R, float alpha, const float* alpha_dev, int accumulate, hipStream_t st) {
-    auto kern = gemm_mfma_kernel<A_COL, B_COL, GLDS>;
+           int64_t ldc, const void* R, float alpha, const float* alpha_dev, int accumulate, hipStream_t st,
+           int splits = 1, float* slabs = nullptr) {
+    auto kern = gemm_mfma_kernel<A_COL, B_COL, SPLITK>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) { ssi_set_error("gemm_mfma: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return SSI_ERR_HIP + (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(NTHREADS), LDS_BYTES, st, tiles_m, tiles_n, K,
-                       (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (const bf16_t*)R, alpha, alpha_dev,
-                       accumulate);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n), (unsigned)splits), dim3(NTHREADS), LDS_BYTES, st, tiles_m,
+                       tiles_n, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (const bf16_t*)R, alpha,
+                       alpha_dev, accumulate, slabs);
     SSI_LAUNCH_CHECK();
+    if (SPLITK) {
+        const int64_t M = (int64_t)tiles_m * BM, N = (int64_t)tiles_n * BN;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ssi_cdiv(M * N / 8, 256)), dim3(256), 0, st, slabs, splits, M, N,
+                           (bf16_t*)C, ldc, (const bf16_t*)R, alpha, alpha_dev, accumulate);
+        SSI_LAUNCH_CHECK();
+    }
     return SSI_OK;
 }
 
-bool use_glds() { return ssi_get_impl() != SSI_IMPL_MFMA_REGSTAGE; }  // default: LDS-DMA staging
 
 }  // namespace
 
@@ -243,10 +324,22 @@ int ssi_gemm_mfma_bf16(int layout, int64_t M, int64_t N, int64_t K, const void* 
                        int accumulate, void* stream) {
     const int tm = (int)(M / BM), tn = (int)(N / BN);
     auto st = (hipStream_t)stream;
-    const bool g = use_glds();
-#define GO(AC, BC)                                                                                                     \
-    return g ? launch<AC, BC, true>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, accumulate, st)            \
-             : launch<AC, BC, false>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, accumulate, st)
+#define GO(AC, BC) return launch<AC, BC, false>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, accumulate, st)
+    switch (layout) {
+        case SSI_GEMM_NT: GO(false, false);
+        case SSI_GEMM_NN: GO(false, true);
+        case SSI_GEMM_TN: GO(true, true);
+    }
+#undef GO
+    return SSI_ERR_ARG;
+}
+
+int ssi_gemm_mfma_bf16_splitk(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                              int64_t ldb, void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev,
+                              int accumulate, int splits, float* slabs, void* stream) {
+    const int tm = (int)(M / BM), tn = (int)(N / BN);
+    auto st = (hipStream_t)stream;
+#define GO(AC, BC) return launch<AC, BC, true>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, accumulate, st, splits, slabs)
     switch (layout) {
         case SSI_GEMM_NT: GO(false, false);
         case SSI_GEMM_NN: GO(false, true);

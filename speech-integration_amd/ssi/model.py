@@ -333,6 +333,17 @@ class HipLlamaDecoder(nn.Module):
         self._grads_dirty = True
         gv = lambda name: self._view(name, None, G)  # noqa: E731
         ws = A.get("ws.rms", (max(ops.rmsnorm_bwd_workspace_bytes(T, D), 16),), torch.uint8)
+
+        def wgrad(dy: Tensor, x: Tensor, name: str) -> None:
+            """dW += dy^T x; split over K = tokens when the [out, in] grid cannot fill the chip (square projections)."""
+            g = gv(name)
+            splits = ops.splitk_choice(g.shape[0], g.shape[1], T) if (dt == torch.bfloat16 and T % 64 == 0) else 1
+            if splits > 1:
+                wsk = A.get("ws.splitk", (splits * g.shape[0] * g.shape[1],), torch.float32)
+                ops.gemm_splitk(GEMM_TN, dy, x, g, splits, wsk, accumulate=True)
+            else:
+                ops.gemm(GEMM_TN, dy, x, g, accumulate=True)
+
         sync = self.grad_sync if (self.grad_sync is not None and self.sync_this_backward) else None
 
         dh = A.get("dh.a", (T, D), dt)
@@ -348,25 +359,25 @@ class HipLlamaDecoder(nn.Module):
             # MLP: h_out = hmid + act @ w2^T
             dact = A.get("dact", (T, I), dt)
             ops.gemm(GEMM_NN, dh, self._view(f"L{l}.w2"), dact)
-            ops.gemm(GEMM_TN, dh, act, gv(f"L{l}.w2"), accumulate=True)
+            wgrad(dh, act, f"L{l}.w2")
             dgu = A.get("dgu", (T, 2 * I), dt)
             ops.swiglu_bwd(dact, gu, dgu)
             dxn = A.get("dxn", (T, D), dt)
             ops.gemm(GEMM_NN, dgu, self._view(f"L{l}.w13"), dxn)
-            ops.gemm(GEMM_TN, dgu, xn2, gv(f"L{l}.w13"), accumulate=True)
+            wgrad(dgu, xn2, f"L{l}.w13")
             dhmid = A.get("dh.b", (T, D), dt)
             ops.rmsnorm_bwd(dxn, hmid, self._view(f"L{l}.mlp_norm"), A.get(f"rstd2.{l}", (T,), torch.float32), dh, dhmid,
                             gv(f"L{l}.mlp_norm"), ws)
             # attention: hmid = h_in + att @ wo^T
             datt = A.get("datt", (T, H * hd), dt)
             ops.gemm(GEMM_NN, dhmid, self._view(f"L{l}.wo"), datt)
-            ops.gemm(GEMM_TN, dhmid, att, gv(f"L{l}.wo"), accumulate=True)
+            wgrad(dhmid, att, f"L{l}.wo")
             dqkv = A.get("dqkv", (T, self.qkv_dim), dt)
             delta = A.get("delta", (B * H * S,), torch.float32)
             ops.attn_bwd(qkv, att, datt, A.get(f"lse.{l}", (B * H * S,), torch.float32), dqkv, delta, B, S, H, KV, hd)
             ops.rope_(dqkv, S, H + KV, hd, self._rope, inverse=True)
             ops.gemm(GEMM_NN, dqkv, self._view(f"L{l}.wqkv"), dxn)
-            ops.gemm(GEMM_TN, dqkv, xn1, gv(f"L{l}.wqkv"), accumulate=True)
+            wgrad(dqkv, xn1, f"L{l}.wqkv")
             ops.rmsnorm_bwd(dxn, h_in, self._view(f"L{l}.sa_norm"), A.get(f"rstd1.{l}", (T,), torch.float32), dhmid, dh,
                             gv(f"L{l}.sa_norm"), ws)
             if sync:

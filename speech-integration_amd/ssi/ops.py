@@ -10,7 +10,7 @@ from . import _lib
 from ._lib import GEMM_NN, GEMM_NT, GEMM_TN, check, dtype_code, ptr, stream_ptr
 
 __all__ = ["embed_fwd", "embed_bwd", "rmsnorm_fwd", "rmsnorm_bwd", "rope_", "attn_fwd", "attn_bwd", "swiglu_fwd",
-           "swiglu_bwd", "gemm", "ce_fwd", "ce_reduce", "count_tokens", "scale_", "sumsq", "adamw_step", "set_impl",
+           "swiglu_bwd", "gemm", "gemm_splitk", "splitk_choice", "ce_fwd", "ce_reduce", "count_tokens", "scale_", "sumsq", "adamw_step", "set_impl",
            "GEMM_NT", "GEMM_NN", "GEMM_TN"]
 
 
@@ -132,6 +132,37 @@ def gemm(layout: int, a: Tensor, b: Tensor, c: Tensor, *, residual: Tensor | Non
     check(_lib.load().ssi_gemm(layout, M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(c), c.stride(0),
                                ptr(residual), alpha, ptr(alpha_dev), int(accumulate), dtype_code(c.dtype), stream_ptr()),
           "ssi_gemm")
+
+
+def splitk_choice(M: int, N: int, K: int, n_cu: int = 256) -> int:
+    """Number of K-slices for a 256x256-tiled MFMA GEMM: minimise (waves of workgroups) x (K-tiles per slice) plus the slab
+    write + read traffic; 1 when the output grid already fills the chip."""
+    if M % 256 or N % 256 or K % 64:
+        return 1
+    tiles, nk = (M // 256) * (N // 256), K // 64
+    if tiles >= n_cu:
+        return 1
+    best, best_t = 1, None
+    for s in (1, 2, 3, 4, 6, 8, 12, 16):
+        if s > nk:
+            break
+        waves = -(-tiles * s // n_cu)
+        t = waves * -(-nk // s) * 1.8e-6 + ((s + 1) * M * N * 4 / 4.0e12 if s > 1 else 0.0)
+        if best_t is None or t < best_t * 0.97:
+            best, best_t = s, t
+    return best
+
+
+def gemm_splitk(layout: int, a: Tensor, b: Tensor, c: Tensor, splits: int, workspace: Tensor, *, alpha: float = 1.0,
+                alpha_dev: Tensor | None = None, accumulate: bool = False) -> None:
+    if splits <= 1:
+        return gemm(layout, a, b, c, alpha=alpha, alpha_dev=alpha_dev, accumulate=accumulate)
+    M, N = c.shape
+    K = a.shape[1] if layout in (GEMM_NT, GEMM_NN) else a.shape[0]
+    assert a.stride(1) == 1 and b.stride(1) == 1 and c.stride(1) == 1 and a.dtype == b.dtype == c.dtype
+    check(_lib.load().ssi_gemm_splitk(layout, M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(c), c.stride(0), None,
+                                      alpha, ptr(alpha_dev), int(accumulate), dtype_code(c.dtype), splits, ptr(workspace),
+                                      workspace.numel() * workspace.element_size(), stream_ptr()), "ssi_gemm_splitk")
 
 
 def ce_fwd(logits: Tensor, labels: Tensor, vocab: int, ignore_index: int, row_loss: Tensor, row_lse: Tensor | None,

@@ -254,7 +254,7 @@ def test_gemm_generic(ops, dtype, layout, M, N, K):
         ops.set_impl(prev)
 
 
-@pytest.mark.parametrize("impl_name", ["IMPL_MFMA", "IMPL_MFMA_REGSTAGE"])
+@pytest.mark.parametrize("impl_name", ["IMPL_MFMA"])
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 192), (1024, 256, 2048)])
 def test_gemm_mfma_bf16(ops, impl_name, layout, M, N, K):
@@ -381,3 +381,26 @@ def test_attention_mfma_fwd_bwd(ops, B, S, H, KV):
         assert torch.equal(out2.cpu().float(), out) and torch.equal(d2.cpu().float(), dqkv)
     finally:
         ops.set_impl(prev)
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("splits", [2, 3, 8])
+def test_gemm_splitk_matches_direct(ops, layout, splits):
+    from ssi import _lib
+    M, N, K = 512, 256, 1024  # 16 K-tiles: uneven slices for splits=3
+    a, b = _gemm_operands(layout, M, N, K, torch.bfloat16, 30)
+    c0 = rnd(M, N, dtype=torch.bfloat16, seed=31)
+    alpha_dev = torch.tensor([0.5], device=DEV)
+    direct, split = c0.to(DEV), c0.to(DEV)
+    ops.gemm(layout, a.to(DEV), b.to(DEV), direct, alpha=2.0, alpha_dev=alpha_dev, accumulate=True)
+    need = _lib.load().ssi_gemm_splitk_workspace_bytes(M, N, splits)
+    assert need == splits * M * N * 4
+    ws = torch.empty(need // 4, dtype=torch.float32, device=DEV)
+    ops.gemm_splitk(layout, a.to(DEV), b.to(DEV), split, splits, ws, alpha=2.0, alpha_dev=alpha_dev, accumulate=True)
+    ref = (_gemm_ref(layout, a, b).float().bfloat16().double() + c0.double())
+    torch.testing.assert_close(split.cpu().double(), ref, rtol=2e-2, atol=0.03 * math.sqrt(K))
+    diff = (split.float() - direct.float()).abs()  # fp32 partial sums in a different order: at most 1 bf16 ulp apart
+    assert float(diff.max()) <= 2 ** -6 * float(direct.float().abs().max())
+    with pytest.raises(RuntimeError):
+        ops.gemm_splitk(layout, a.to(DEV), b.to(DEV), split, splits, ws[:16])
+    assert ops.splitk_choice(2048, 2048, 16384) > 1 and ops.splitk_choice(16384, 2048, 16384) == 1
