@@ -102,6 +102,11 @@ int ssi_gemm_splitk(int layout, int64_t M, int64_t N, int64_t K, const void* A, 
                     void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev, int accumulate, int dtype,
                     int splits, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* dst[c][r] = src[r][c] for a [rows, cols] matrix (both dims multiples of 8).  Keeps [in, out] copies of the projection
+ * weights so that the data-gradient GEMMs use the k-contiguous operand form (refreshed once per optimizer step). */
+int ssi_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols, int dtype,
+                  void* stream);
+
 /* ---- K9  CEWithChunkedOutputLoss (ssi/trainer.py:300; F.cross_entropy(logits.float(), reduction="sum")) -------------- */
 /* logits: [rows, ld] (columns [0, vocab) are real, [vocab, ld) padding).  labels: already shifted (ssi/loss.py:16).
  * row_loss[r] = lse(logits[r]) - logits[r, label] (0 if ignored).  If write_grad: logits[r, :] is OVERWRITTEN by

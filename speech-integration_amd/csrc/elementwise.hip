@@ -476,3 +476,49 @@ extern "C" int ssi_adamw_step(void* param, void* grad, void* exp_avg, void* exp_
     SSI_LAUNCH_CHECK();
     return SSI_OK;
 }
+
+// =====================================================================================================================
+// 2-D transpose dst[c][r] = src[r][c] (64 x 64 tiles through LDS; 16-B global accesses on both sides).  Used once per
+// optimizer step to refresh the [in, out] copies of the projection weights, so that the data-gradient GEMMs
+// dX = dY W run in the k-contiguous (NT) operand form instead of the transposed-read form.
+// =====================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, int64_t lds_, T* __restrict__ dst, int64_t ldd,
+                                                        int64_t rows, int64_t cols) {
+    constexpr int N = Vec16<T>::N;          // elements per 16 B
+    constexpr int TS = 64;                  // tile edge
+    __shared__ T tile[TS][TS + 2 * N / N + 2];  // +pad breaks the power-of-two row stride
+    const int64_t r0 = (int64_t)blockIdx.y * TS, c0 = (int64_t)blockIdx.x * TS;
+    constexpr int VPR = TS / N;             // vectors per tile row
+    for (int v = threadIdx.x; v < TS * VPR; v += 256) {
+        const int r = v / VPR, cv = (v % VPR) * N;
+        if (r0 + r < rows && c0 + cv < cols) {
+            Vec16<T> a = load16(src + (r0 + r) * lds_ + c0 + cv);
+#pragma unroll
+            for (int i = 0; i < N; ++i) tile[cv + i][r] = from_f32<T>(a.get(i));
+        }
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < TS * VPR; v += 256) {
+        const int c = v / VPR, rv = (v % VPR) * N;
+        if (c0 + c < cols && r0 + rv < rows) {
+            Vec16<T> o;
+#pragma unroll
+            for (int i = 0; i < N; ++i) o.set(i, to_f32<T>(tile[c][rv + i]));
+            store16(dst + (c0 + c) * ldd + r0 + rv, o);
+        }
+    }
+}
+
+extern "C" int ssi_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols, int dtype,
+                             void* stream) {
+    SSI_CHECK_ARG(src && dst && rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= rows);
+    SSI_CHECK_ARG(rows % 8 == 0 && cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0);
+    if (rows == 0 || cols == 0) return SSI_OK;
+    SSI_CHECK_ARG(ssi_cdiv(rows, 64) <= 65535);
+    dim3 grid((unsigned)ssi_cdiv(cols, 64), (unsigned)ssi_cdiv(rows, 64));
+    SSI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src, ld_src,
+                                                 (T*)dst, ld_dst, rows, cols));
+    SSI_LAUNCH_CHECK();
+    return SSI_OK;
+}

@@ -136,9 +136,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
         stage_tile<B_COL>(B, ldb, n0, kofs + (int64_t)kt * BK, tileB(buf), tid);
     };
     // Fragment registers: the wave's 128 x 64 tile is walked as 2 row halves (4 m-tiles each) x 2 k-halves per K-tile.
-    // a0/a1 alternate between the row halves, b0/b1 between the k-halves, so every block of 16 MFMAs runs while the
-    // ds_reads of the NEXT block are in flight (the two waves of a SIMD then interleave MFMA and LDS work instead of
-    // colliding on each in lockstep).
+    // a0/a1 alternate between the row halves, b0/b1 between the k-halves; the ds_reads of the NEXT block are issued one
+    // per MFMA of the current block (sched_group_barrier), so LDS reads stream continuously under the matrix pipe
+    // (measured +6 % on the k-contiguous form; the transposed-read forms are bound by ds_read_b64_tr_b16 itself:
+    // replacing them by plain ds_read_b64 of the same addresses recovers the k-contiguous rate — DESIGN.md).
     bf16x8 a0[4], a1[4], b0[4], b1[4];
     auto readA = [&](bf16x8 (&dst)[4], const char* la, int half, int kh) {
 #pragma unroll
@@ -149,14 +150,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
         for (int j = 0; j < 4; ++j) dst[j] = read_frag<B_COL>(lb, wn * WN + j * 16, kh, lane);
     };
     auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[4], int half) {
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[j][half * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][half * 4 + i], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
     };
+    // ask the scheduler for: 1 MFMA, then up to RPM ds_reads, 16 times (reads of the NEXT block ride between the MFMAs)
+#define INTERLEAVE(RPM)                                                        \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);                   \
+    }
 
     stage(0, 0);
     if (nk > 1) stage(1, 1);
@@ -170,11 +175,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
         const char* lb = tileB(cur);
         readA(a1, la, 1, 0);
         mma(a0, b0, 0);
+        INTERLEAVE(1);
+        __builtin_amdgcn_sched_barrier(0);
         readA(a0, la, 0, 1);
         readB(b1, lb, 1);
         mma(a1, b0, 1);
+        INTERLEAVE(1);
+        __builtin_amdgcn_sched_barrier(0);
         readA(a1, la, 1, 1);
         mma(a0, b1, 0);
+        INTERLEAVE(1);
+        __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nk) {
             // hipcc does not reliably order LDS-DMA against later ds_reads of another buffer: wait explicitly
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -184,6 +195,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
             readB(b0, tileB(cur ^ 1), 0);
         }
         mma(a1, b1, 1);
+        INTERLEAVE(1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- epilogue: acc[j][i] holds C[m = wm*128 + i*16 + (lane&15)][n = wn*64 + j*16 + (lane>>4)*4 + r] ----------------

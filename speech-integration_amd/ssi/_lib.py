@@ -14,7 +14,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libssi_hip.so")
+LIB_PATH = os.environ.get("SSI_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libssi_hip.so")  # override: diagnostic builds
 
 SSI_F32, SSI_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
@@ -43,6 +43,7 @@ PROTOTYPES = {
     "ssi_gemm_splitk_workspace_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "ssi_gemm_splitk": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_float, _P,
                                 c_int, c_int, c_int, _P, c_int64, _P]),
+    "ssi_transpose": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int, _P]),
     "ssi_ce_fwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, c_int, c_int, _P]),
     "ssi_ce_reduce": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
     "ssi_count_tokens": (c_int, [_P, _P, c_int64, _P, c_int, c_int64, c_int64, _P, _P]),

@@ -146,6 +146,11 @@ class HipLlamaDecoder(nn.Module):
         self._flat_numel = off
         self._flat = torch.zeros(off, dtype=dtype, device=device)
         self._flat_grad = torch.zeros(off, dtype=dtype, device=device)
+        # [in, out] copies of the 2-D weights (same offsets, transposed shapes): data-gradient GEMMs dX = dY W then run in
+        # the k-contiguous operand form (the transposed-read form is ~20 % slower); refreshed lazily
+        self._flat_t: Optional[Tensor] = None
+        self._wt_key: Optional[tuple] = None
+        self._hip_epoch = 0  # bumped by kernels that modify the weights in place (fused AdamW)
         self._grad_views: dict[str, Tensor] = {}
         # DP buckets in the order backward finishes them: final norm, layers L-1..0, embedding (tied: finished last)
         self.buckets: list[tuple[str, int, int]] = []
@@ -241,6 +246,25 @@ class HipLlamaDecoder(nn.Module):
                         raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(src.shape)} vs model {tuple(p.shape)}")
                     p.copy_(src.to(device=self.device, dtype=self.dtype))
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def _view_t(self, name: str) -> Tensor:
+        o, shape = self._slices[name]
+        return self._flat_t[o:o + shape[0] * shape[1]].view(shape[1], shape[0])
+
+    def _ensure_transposed(self) -> bool:
+        """Refresh the transposed weight copies if any weight changed since the last refresh.  Returns whether the
+        transposed copies are in use (bf16 MFMA shapes only)."""
+        if not self._mfma_shapes():
+            return False
+        key = (self._flat._version, self._hip_epoch)
+        if self._flat_t is None:
+            self._flat_t = torch.empty_like(self._flat)
+        if key != self._wt_key:
+            for name, (o, shape) in self._slices.items():
+                if len(shape) == 2:
+                    ops.transpose(self._view(name), self._view_t(name))
+            self._wt_key = key
+        return True
 
     def attach_grads(self) -> None:
         """Point every ``p.grad`` at its slice of the flat gradient buffer (idempotent)."""
@@ -345,6 +369,14 @@ class HipLlamaDecoder(nn.Module):
                 ops.gemm(GEMM_TN, dy, x, g, accumulate=True)
 
         sync = self.grad_sync if (self.grad_sync is not None and self.sync_this_backward) else None
+        use_t = self._ensure_transposed()
+
+        def dgrad(dy: Tensor, name: str, dx: Tensor) -> None:
+            """dx = dy @ W  (W = [out, in]); NT form on the [in, out] copy when available."""
+            if use_t:
+                ops.gemm(GEMM_NT, dy, self._view_t(name), dx)
+            else:
+                ops.gemm(GEMM_NN, dy, self._view(name), dx)
 
         dh = A.get("dh.a", (T, D), dt)
         ops.rmsnorm_bwd(d_hn, A.get(f"h{L}", (T, D), dt), self.norm.scale, A.get("rstdf", (T,), torch.float32), None, dh,
@@ -358,25 +390,25 @@ class HipLlamaDecoder(nn.Module):
             h_in = A.get(f"h{l}", (T, D), dt)
             # MLP: h_out = hmid + act @ w2^T
             dact = A.get("dact", (T, I), dt)
-            ops.gemm(GEMM_NN, dh, self._view(f"L{l}.w2"), dact)
+            dgrad(dh, f"L{l}.w2", dact)
             wgrad(dh, act, f"L{l}.w2")
             dgu = A.get("dgu", (T, 2 * I), dt)
             ops.swiglu_bwd(dact, gu, dgu)
             dxn = A.get("dxn", (T, D), dt)
-            ops.gemm(GEMM_NN, dgu, self._view(f"L{l}.w13"), dxn)
+            dgrad(dgu, f"L{l}.w13", dxn)
             wgrad(dgu, xn2, f"L{l}.w13")
             dhmid = A.get("dh.b", (T, D), dt)
             ops.rmsnorm_bwd(dxn, hmid, self._view(f"L{l}.mlp_norm"), A.get(f"rstd2.{l}", (T,), torch.float32), dh, dhmid,
                             gv(f"L{l}.mlp_norm"), ws)
             # attention: hmid = h_in + att @ wo^T
             datt = A.get("datt", (T, H * hd), dt)
-            ops.gemm(GEMM_NN, dhmid, self._view(f"L{l}.wo"), datt)
+            dgrad(dhmid, f"L{l}.wo", datt)
             wgrad(dhmid, att, f"L{l}.wo")
             dqkv = A.get("dqkv", (T, self.qkv_dim), dt)
             delta = A.get("delta", (B * H * S,), torch.float32)
             ops.attn_bwd(qkv, att, datt, A.get(f"lse.{l}", (B * H * S,), torch.float32), dqkv, delta, B, S, H, KV, hd)
             ops.rope_(dqkv, S, H + KV, hd, self._rope, inverse=True)
-            ops.gemm(GEMM_NN, dqkv, self._view(f"L{l}.wqkv"), dxn)
+            dgrad(dqkv, f"L{l}.wqkv", dxn)
             wgrad(dqkv, xn1, f"L{l}.wqkv")
             ops.rmsnorm_bwd(dxn, h_in, self._view(f"L{l}.sa_norm"), A.get(f"rstd1.{l}", (T,), torch.float32), dhmid, dh,
                             gv(f"L{l}.sa_norm"), ws)
@@ -401,7 +433,10 @@ class HipLlamaDecoder(nn.Module):
         T, D = hn.shape
         self._grads_dirty = True
         d_hn = self._arena.get("d_hn", (T, D), self.dtype)
-        ops.gemm(GEMM_NN, dlogits, self._view("emb"), d_hn, alpha_dev=alpha_dev)
+        if self._ensure_transposed():
+            ops.gemm(GEMM_NT, dlogits, self._view_t("emb"), d_hn, alpha_dev=alpha_dev)
+        else:
+            ops.gemm(GEMM_NN, dlogits, self._view("emb"), d_hn, alpha_dev=alpha_dev)
         ops.gemm(GEMM_TN, dlogits, hn, self._view("emb", None, self._flat_grad), alpha_dev=alpha_dev, accumulate=True)
         return d_hn
 

@@ -10,7 +10,7 @@ from . import _lib
 from ._lib import GEMM_NN, GEMM_NT, GEMM_TN, check, dtype_code, ptr, stream_ptr
 
 __all__ = ["embed_fwd", "embed_bwd", "rmsnorm_fwd", "rmsnorm_bwd", "rope_", "attn_fwd", "attn_bwd", "swiglu_fwd",
-           "swiglu_bwd", "gemm", "gemm_splitk", "splitk_choice", "ce_fwd", "ce_reduce", "count_tokens", "scale_", "sumsq", "adamw_step", "set_impl",
+           "swiglu_bwd", "gemm", "gemm_splitk", "splitk_choice", "transpose", "ce_fwd", "ce_reduce", "count_tokens", "scale_", "sumsq", "adamw_step", "set_impl",
            "GEMM_NT", "GEMM_NN", "GEMM_TN"]
 
 
@@ -163,6 +163,14 @@ def gemm_splitk(layout: int, a: Tensor, b: Tensor, c: Tensor, splits: int, works
     check(_lib.load().ssi_gemm_splitk(layout, M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(c), c.stride(0), None,
                                       alpha, ptr(alpha_dev), int(accumulate), dtype_code(c.dtype), splits, ptr(workspace),
                                       workspace.numel() * workspace.element_size(), stream_ptr()), "ssi_gemm_splitk")
+
+
+def transpose(src: Tensor, dst: Tensor) -> None:
+    """dst[c, r] = src[r, c] (2-D, unit inner stride, dims multiples of 8)."""
+    assert src.dim() == 2 and dst.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1 and src.dtype == dst.dtype
+    assert dst.shape == (src.shape[1], src.shape[0])
+    check(_lib.load().ssi_transpose(ptr(src), src.stride(0), ptr(dst), dst.stride(0), src.shape[0], src.shape[1],
+                                    dtype_code(src.dtype), stream_ptr()), "ssi_transpose")
 
 
 def ce_fwd(logits: Tensor, labels: Tensor, vocab: int, ignore_index: int, row_loss: Tensor, row_lse: Tensor | None,

@@ -59,6 +59,7 @@ class HipAdamW(torch.optim.Optimizer):
                        grad_scale_dev=m.pending_grad_scale, zero_grad=True)
         m.pending_grad_scale = None
         m._grads_dirty = False
+        m._hip_epoch += 1  # weights changed behind torch's version counter
         if self._views_ready:
             for st in self.state.values():
                 st["step"].fill_(float(self._step_count))

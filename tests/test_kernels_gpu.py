@@ -404,3 +404,12 @@ def test_gemm_splitk_matches_direct(ops, layout, splits):
     with pytest.raises(RuntimeError):
         ops.gemm_splitk(layout, a.to(DEV), b.to(DEV), split, splits, ws[:16])
     assert ops.splitk_choice(2048, 2048, 16384) > 1 and ops.splitk_choice(16384, 2048, 16384) == 1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,cols", [(64, 64), (200, 136), (2048, 3072)])
+def test_transpose(ops, dtype, rows, cols):
+    src = rnd(rows, cols, dtype=dtype, seed=32)
+    dst = torch.empty(cols, rows, dtype=dtype, device=DEV)
+    ops.transpose(src.to(DEV), dst)
+    assert torch.equal(dst.cpu(), src.t().contiguous())  # bit-exact data movement

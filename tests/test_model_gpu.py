@@ -229,3 +229,46 @@ def test_trainer_three_steps_match_cpu_step_oracle(tmp_path, dtype_name, tol):
 def itertools_islice(loader, n):
     import itertools
     return list(itertools.islice(iter(loader), n))
+
+
+def test_bf16_mfma_shaped_model_matches_oracle_and_refreshes_transposed_weights():
+    """A model whose dims satisfy the MFMA tile rules (so the MFMA GEMMs, split-K weight gradients, the transposed-weight
+    data-gradient path and MFMA attention all run), against the fp32 CPU oracle; then an optimizer step must refresh the
+    transposed weight copies."""
+    from oracle import hf_crosscheck as hx
+    from oracle.llama_oracle import OracleCEWithChunkedOutputLoss
+    from oracle.llama_oracle import compute_loss as oracle_loss
+    from ssi.loss import CEWithChunkedOutputLoss, compute_loss
+    from ssi.model import HipLlamaDecoder
+    from ssi.optimizer import HipAdamW, scale_grads
+    params = dict(vocab_size=700, num_layers=2, num_heads=4, num_kv_heads=2, embed_dim=256, max_seq_len=512, intermediate_dim=512)
+    sd = hx.seeded_state_dict(params, 21)
+    batch = hx.seeded_batch(700, 2, 128, 21)
+    model = HipLlamaDecoder(**params, dtype=torch.bfloat16, device=DEV)
+    model.load_state_dict(sd)
+    assert model._mfma_shapes()
+    ref_model = hx.oracle_model(params, sd)
+    ref = oracle_loss(batch, ref_model, OracleCEWithChunkedOutputLoss())
+    ref.backward()
+    dbatch = _to_dev(batch)
+    loss = compute_loss(dbatch, model, CEWithChunkedOutputLoss())
+    loss.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-2 * abs(ref.item())
+    assert model._flat_t is not None
+    for name in ("emb", "L0.wqkv", "L1.w2"):
+        assert torch.equal(model._view_t(name), model._view(name).t())
+    for (k, p), (_, p2) in zip(model.named_parameters(), ref_model.named_parameters()):
+        g, g2 = p.grad.float().cpu(), p2.grad
+        rel = float((g - g2).norm() / g2.norm())
+        assert rel <= 6e-2, f"{k}: relative gradient error {rel}"
+    key_before = model._wt_key
+    opt = HipAdamW(model.parameters(), model=model, lr=1e-2)
+    scale_grads(model, torch.tensor(1.0))
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    l2 = compute_loss(dbatch, model, CEWithChunkedOutputLoss())
+    l2.backward()
+    assert model._wt_key != key_before
+    for name in ("emb", "L0.wqkv", "L1.w2"):
+        assert torch.equal(model._view_t(name), model._view(name).t())
+    assert l2.item() < loss.item()  # the step reduced the loss on the same batch
