@@ -88,7 +88,7 @@ template <int ROWS, int NTHR> struct TileStage {
 // forward
 // =====================================================================================================================
 // grid.x = B * KV * (S / (32 * QPW)),  QPW = 4 / rep q-blocks per workgroup; wave w: head kvh*rep + w % rep, q-block w / rep
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t ld, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t ld, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, int S, int H, int KV) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];  // [buf][K|V][64][64] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // =====================================================================================================================
 // backward: dQ   (same decomposition as the forward)
 // =====================================================================================================================
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S,
                                                           int H, int KV) {
@@ -335,11 +335,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 // backward: dK, dV.  Workgroup = (b, kv head, 32-key block); its 4 waves split (query head of the group, q-block
 // stripe); each keeps dK^T and dV^T of the 32 keys in accumulators over its sweep; one LDS reduction at the end.
 // =====================================================================================================================
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+__device__ __forceinline__ void dma_tile32(const bf16_t* g, int64_t ld, char* lds_tile, int lane) {
+    // [32][64] bf16 tile = 4 KiB = 4 LDS-DMA instructions of 8 rows x 128 B; row swizzle applied on the source address
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = p * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz<SWZ_ROW>(row);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(g + (int64_t)row * ld + chunk * 8),
+                                         (__attribute__((address_space(3))) void*)(lds_tile + p * 1024), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S,
                                                            int H, int KV) {
-    // per wave: Q tile [32][64] + dO tile [32][64] (4 KiB each); reused at the end as [4 waves][2][64 d][32 keys] fp32
+    // per wave: 2 buffers x (Q tile [32][64] + dO tile [32][64]) = 16 KiB, filled by LDS-DMA one tile ahead; the same
+    // 64 KiB are reused at the end as [4 waves][2][64 d][32 keys] fp32 for the cross-wave reduction
     __shared__ __attribute__((aligned(16))) char smem[4 * 2 * 64 * 32 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep = H / KV, stripes = 4 / rep;
@@ -351,10 +363,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     const int stripe = wave / rep;
     const int h = lane >> 5;
     const int64_t row0 = (int64_t)b * S;
+    const int64_t ldo = (int64_t)H * HD;
     const int key0 = kblk * 32;
     const int kg = key0 + (lane & 31);
-    char* qt = smem + wave * 8192;
-    char* dt = qt + 4096;
+    char* wbuf = smem + wave * 16384;
 
     // K (pre-scaled by 2^-3) and V as B operands: lane holds row key0 + (l & 31), d = 16 ks + 8 h + j
     bf16x8 kf[4], vf[4];
@@ -372,58 +384,62 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
-    const int nq_total = nkb - kblk;                       // q-blocks kblk .. nkb-1
-    const int trips = (nq_total + stripes - 1) / stripes;  // uniform trip count for the barriers
-    TileStage<32, 64> sq, sd;
-    for (int it = 0; it < trips; ++it) {
-        const int qb = kblk + it * stripes + stripe;
-        const bool active = qb < nkb;  // wave-uniform
-        const int q0 = qb * 32;
-        if (active) {
-            sq.load(qkv + (row0 + q0) * ld + (int64_t)head * HD, ld, lane);
-            sd.load(dout + (row0 + q0) * ((int64_t)H * HD) + (int64_t)head * HD, (int64_t)H * HD, lane);
-            sq.store<SWZ_ROW>(qt, lane);
-            sd.store<SWZ_ROW>(dt, lane);
-        }
-        __syncthreads();
-        if (active) {
-            f32x16 sacc, pacc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(qt, 0, ks, lane), kf[ks], sacc, 0, 0, 0);
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(dt, 0, ks, lane), vf[ks], pacc, 0, 0, 0);
-            }
-            // rows of the accumulators are queries q0 + rowmap(r, h); row constants come in runs of 4
-            const float* lrow = lse + ((int64_t)b * H + head) * S + q0 + 4 * h;
-            const float* drow = delta + ((int64_t)b * H + head) * S + q0 + 4 * h;
-            const bool diag = q0 < key0 + 32;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lrow + 8 * g);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(drow + 8 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    float p = __builtin_amdgcn_exp2f(sacc[r] * LOG2E - l4[e] * LOG2E);
-                    if (diag && kg > q0 + rowmap(r, h)) p = 0.f;
-                    sacc[r] = p;
-                    pacc[r] = p * (pacc[r] - d4[e]);
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 pf = acc_frag(sacc, s), dsf = acc_frag(pacc, s);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(dt, s * 16, db * 32, lane), pf, dv[db], 0, 0, 0);
-                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(qt, s * 16, db * 32, lane), dsf, dk[db], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
+    const int n_mine = (nkb - kblk - stripe + stripes - 1) / stripes;  // q-blocks kblk + stripe, + stripes, ... < nkb
+    auto q_tile = [&](int it) { return qkv + (row0 + (int64_t)(kblk + stripe + it * stripes) * 32) * ld + (int64_t)head * HD; };
+    auto do_tile = [&](int it) { return dout + (row0 + (int64_t)(kblk + stripe + it * stripes) * 32) * ldo + (int64_t)head * HD; };
+    if (n_mine > 0) {
+        dma_tile32(q_tile(0), ld, wbuf, lane);
+        dma_tile32(do_tile(0), ldo, wbuf + 4096, lane);
     }
+    for (int it = 0; it < n_mine; ++it) {
+        const int q0 = (kblk + stripe + it * stripes) * 32;
+        const char* qt = wbuf + (it & 1) * 8192;
+        const char* dt = qt + 4096;
+        // row constants of the accumulator rows (queries q0 + rowmap(r, h)), runs of 4; requested before the DMA wait
+        const float* lrow = lse + ((int64_t)b * H + head) * S + q0 + 4 * h;
+        const float* drow = delta + ((int64_t)b * H + head) * S + q0 + 4 * h;
+        f32x4 l4[4], d4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            l4[g] = *reinterpret_cast<const f32x4*>(lrow + 8 * g);
+            d4[g] = *reinterpret_cast<const f32x4*>(drow + 8 * g);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's DMA (wave-private region) has landed
+        if (it + 1 < n_mine) {  // next tile into the other buffer (its readers finished one iteration ago)
+            char* nb = wbuf + ((it + 1) & 1) * 8192;
+            dma_tile32(q_tile(it + 1), ld, nb, lane);
+            dma_tile32(do_tile(it + 1), ldo, nb + 4096, lane);
+        }
+        f32x16 sacc, pacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(qt, 0, ks, lane), kf[ks], sacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(dt, 0, ks, lane), vf[ks], pacc, 0, 0, 0);
+        }
+        const bool diag = q0 < key0 + 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                float p = __builtin_amdgcn_exp2f(sacc[r] * LOG2E - l4[g][e] * LOG2E);
+                if (diag && kg > q0 + rowmap(r, h)) p = 0.f;
+                sacc[r] = p;
+                pacc[r] = p * (pacc[r] - d4[g][e]);
+            }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 pf = acc_frag(sacc, s), dsf = acc_frag(pacc, s);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(dt, s * 16, db * 32, lane), pf, dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(qt, s * 16, db * 32, lane), dsf, dk[db], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();  // every wave is done with its streaming buffers
     // cross-wave reduction: smem as float [wave][2][64 d][32 keys]
     float* red = reinterpret_cast<float*>(smem) + wave * (2 * 64 * 32);
 #pragma unroll
