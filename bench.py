@@ -131,6 +131,7 @@ def main() -> int:
         if world == 1 and args.gpus > 1:
             print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
             return 2
+    local = int(os.environ.get("SSI_LOCAL_DEVICE", local))  # rehearsal hook: several ranks on one GPU (with SSI_DIST_BACKEND=gloo)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
             dof[ks] = *reinterpret_cast<const bf16x8*>(drow + 16 * ks);
         }
     }
-    const float lb = lse[((int64_t)b * H + head) * S + qg] * LOG2E;
+    const float lq = lse[((int64_t)b * H + head) * S + qg];
     const float dl = delta[((int64_t)b * H + head) * S + qg];
     f32x16 dq[2];
 #pragma unroll
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { sacc[kb][r] = 0.f; pacc[kb][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) { sacc[kb][r] = -lq; pacc[kb][r] = -dl; }  // S'^T = K Q^T - lse, dP'^T = V dO^T - delta
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(kt, kb * 32, ks, lane), qf[ks], sacc[kb], 0, 0, 0);
@@ -300,9 +300,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float p = __builtin_amdgcn_exp2f(sacc[kb][r] * LOG2E - lb);
+                    float p = __builtin_amdgcn_exp2f(sacc[kb][r] * LOG2E);
                     if (diag && k0 + kb * 32 + rowmap(r, h) > qg) p = 0.f;
-                    sacc[kb][r] = p * (pacc[kb][r] - dl);  // dS^T (the 1/sqrt(d) factor is applied once at the end)
+                    sacc[kb][r] = p * pacc[kb][r];  // dS^T (the 1/sqrt(d) factor is applied once at the end)
                 }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -332,41 +332,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 }
 
 // =====================================================================================================================
-// backward: dK, dV.  Workgroup = (b, kv head, 32-key block); its 4 waves split (query head of the group, q-block
-// stripe); each keeps dK^T and dV^T of the 32 keys in accumulators over its sweep; one LDS reduction at the end.
+// backward: dK, dV
 // =====================================================================================================================
-__device__ __forceinline__ void dma_tile32(const bf16_t* g, int64_t ld, char* lds_tile, int lane) {
-    // [32][64] bf16 tile = 4 KiB = 4 LDS-DMA instructions of 8 rows x 128 B; row swizzle applied on the source address
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int row = p * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ swz<SWZ_ROW>(row);
-        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(g + (int64_t)row * ld + chunk * 8),
-                                         (__attribute__((address_space(3))) void*)(lds_tile + p * 1024), 16, 0, 0);
-    }
-}
-
+// Workgroup = (b, kv head, 128-key group); wave w owns keys [key0 + 32 w, +32) and keeps their dK^T / dV^T in accumulators
+// while the workgroup sweeps, for each of the `rep` query heads of the kv head in turn, the Q / dO tiles (32 queries) from
+// the diagonal to the end of the sequence.  The tile of a step is staged ONCE for all four waves (LDS-DMA, double
+// buffered, one step ahead), so Q and dO cross the L2 -> CU path once per 128 keys instead of once per 32, and the sum
+// over the query heads of the group happens in registers: no cross-wave reduction, no partial buffers, one writer per
+// output element.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S,
                                                            int H, int KV) {
-    // per wave: 2 buffers x (Q tile [32][64] + dO tile [32][64]) = 16 KiB, filled by LDS-DMA one tile ahead; the same
-    // 64 KiB are reused at the end as [4 waves][2][64 d][32 keys] fp32 for the cross-wave reduction
-    __shared__ __attribute__((aligned(16))) char smem[4 * 2 * 64 * 32 * 4];
+    // ring of 3 step buffers: [Q tile 4 KiB | dO tile 4 KiB | lse 128 B | delta 128 B]; requests run two steps ahead
+    constexpr int SB = 8192 + 256;
+    __shared__ __attribute__((aligned(16))) char smem[3 * SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rep = H / KV, stripes = 4 / rep;
-    const int nkb = S / 32;
-    const int kblk = (int)(blockIdx.x % nkb);  // low key blocks (most work) are dispatched first
-    const int kvh = (int)(blockIdx.x / nkb) % KV;
-    const int b = (int)(blockIdx.x / nkb) / KV;
-    const int head = kvh * rep + wave % rep;
-    const int stripe = wave / rep;
+    const int rep = H / KV;
+    const int ngrp = S / 128;
+    const int kgrp = (int)(blockIdx.x % ngrp);  // low key groups (most work) are dispatched first
+    const int kvh = (int)(blockIdx.x / ngrp) % KV;
+    const int b = (int)(blockIdx.x / ngrp) / KV;
     const int h = lane >> 5;
     const int64_t row0 = (int64_t)b * S;
     const int64_t ldo = (int64_t)H * HD;
-    const int key0 = kblk * 32;
+    const int key0 = kgrp * 128 + wave * 32;
     const int kg = key0 + (lane & 31);
-    char* wbuf = smem + wave * 16384;
 
     // K (pre-scaled by 2^-3) and V as B operands: lane holds row key0 + (l & 31), d = 16 ks + 8 h + j
     bf16x8 kf[4], vf[4];
@@ -384,88 +375,95 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
-    const int n_mine = (nkb - kblk - stripe + stripes - 1) / stripes;  // q-blocks kblk + stripe, + stripes, ... < nkb
-    auto q_tile = [&](int it) { return qkv + (row0 + (int64_t)(kblk + stripe + it * stripes) * 32) * ld + (int64_t)head * HD; };
-    auto do_tile = [&](int it) { return dout + (row0 + (int64_t)(kblk + stripe + it * stripes) * 32) * ldo + (int64_t)head * HD; };
-    if (n_mine > 0) {
-        dma_tile32(q_tile(0), ld, wbuf, lane);
-        dma_tile32(do_tile(0), ldo, wbuf + 4096, lane);
-    }
-    for (int it = 0; it < n_mine; ++it) {
-        const int q0 = (kblk + stripe + it * stripes) * 32;
-        const char* qt = wbuf + (it & 1) * 8192;
+    const int qb_first = kgrp * 4;          // first 32-query tile that sees any key of the group
+    const int per_head = S / 32 - qb_first;  // tiles per query head
+    const int n_steps = per_head * rep;
+    // step -> (head of the group, query tile); each wave moves one 1-KiB piece of Q and one of dO per step
+    auto issue = [&](int step) {
+        const int head = kvh * rep + step / per_head, q0 = (qb_first + step % per_head) * 32;
+        const int row = wave * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz<SWZ_ROW>(row);
+        char* buf = smem + (step % 3) * SB;
+        __builtin_amdgcn_global_load_lds(
+            (__attribute__((address_space(1))) const void*)(qkv + (row0 + q0 + row) * ld + (int64_t)head * HD + chunk * 8),
+            (__attribute__((address_space(3))) void*)(buf + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(
+            (__attribute__((address_space(1))) const void*)(dout + (row0 + q0 + row) * ldo + (int64_t)head * HD + chunk * 8),
+            (__attribute__((address_space(3))) void*)(buf + 4096 + wave * 1024), 16, 0, 0);
+        // row constants of the tile: lanes 0-31 fetch lse[q0 + l], lanes 32-63 delta[q0 + l - 32] (every wave issues the same
+        // 256-B request so that all waves count 3 requests per step)
+        const float* rc = (lane < 32 ? lse : delta) + ((int64_t)b * H + head) * S + q0 + (lane & 31);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)rc,
+                                         (__attribute__((address_space(3))) void*)(buf + 8192), 4, 0, 0);
+    };
+    issue(0);
+    if (n_steps > 1) issue(1);
+    for (int step = 0; step < n_steps; ++step) {
+        const int q0 = (qb_first + step % per_head) * 32;
+        const char* qt = smem + (step % 3) * SB;
         const char* dt = qt + 4096;
-        // row constants of the accumulator rows (queries q0 + rowmap(r, h)), runs of 4; requested before the DMA wait
-        const float* lrow = lse + ((int64_t)b * H + head) * S + q0 + 4 * h;
-        const float* drow = delta + ((int64_t)b * H + head) * S + q0 + 4 * h;
+        const float* rcs = reinterpret_cast<const float*>(qt + 8192);
+        const bool active = q0 + 31 >= key0;  // wave-uniform: some query of the tile sees some key of this wave
+        // own requests of this step have landed (the next step's 3 may stay in flight) ...
+        if (step + 1 < n_steps) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // ... and everybody else's; the buffer of step-1 is free again
+        if (step + 2 < n_steps) issue(step + 2);
         f32x4 l4[4], d4[4];
+        if (active) {  // row constants of the accumulator rows (queries q0 + rowmap(r, h)), runs of 4
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            l4[g] = *reinterpret_cast<const f32x4*>(lrow + 8 * g);
-            d4[g] = *reinterpret_cast<const f32x4*>(drow + 8 * g);
+            for (int g = 0; g < 4; ++g) {
+                l4[g] = *reinterpret_cast<const f32x4*>(rcs + 4 * h + 8 * g);
+                d4[g] = *reinterpret_cast<const f32x4*>(rcs + 32 + 4 * h + 8 * g);
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's DMA (wave-private region) has landed
-        if (it + 1 < n_mine) {  // next tile into the other buffer (its readers finished one iteration ago)
-            char* nb = wbuf + ((it + 1) & 1) * 8192;
-            dma_tile32(q_tile(it + 1), ld, nb, lane);
-            dma_tile32(do_tile(it + 1), ldo, nb + 4096, lane);
-        }
-        f32x16 sacc, pacc;
+        if (active) {
+            // the row constants ride in as the initial accumulators: S' = Q K^T - lse, dP' = dO V^T - delta
+            f32x16 sacc, pacc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(qt, 0, ks, lane), kf[ks], sacc, 0, 0, 0);
-            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(dt, 0, ks, lane), vf[ks], pacc, 0, 0, 0);
-        }
-        const bool diag = q0 < key0 + 32;
+                for (int e = 0; e < 4; ++e) { sacc[4 * g + e] = -l4[g][e]; pacc[4 * g + e] = -d4[g][e]; }
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int ks = 0; ks < 4; ++ks) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(qt, 0, ks, lane), kf[ks], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(dt, 0, ks, lane), vf[ks], pacc, 0, 0, 0);
+            }
+            const bool diag = q0 < key0 + 32;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g + e;
-                float p = __builtin_amdgcn_exp2f(sacc[r] * LOG2E - l4[g][e] * LOG2E);
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(sacc[r] * LOG2E);
                 if (diag && kg > q0 + rowmap(r, h)) p = 0.f;
                 sacc[r] = p;
-                pacc[r] = p * (pacc[r] - d4[g][e]);
+                pacc[r] *= p;
             }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bf16x8 pf = acc_frag(sacc, s), dsf = acc_frag(pacc, s);
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = acc_frag(sacc, s), dsf = acc_frag(pacc, s);
 #pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(dt, s * 16, db * 32, lane), pf, dv[db], 0, 0, 0);
-                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(qt, s * 16, db * 32, lane), dsf, dk[db], 0, 0, 0);
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(dt, s * 16, db * 32, lane), pf, dv[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(qt, s * 16, db * 32, lane), dsf, dk[db], 0, 0, 0);
+                }
             }
         }
     }
-    __syncthreads();  // every wave is done with its streaming buffers
-    // cross-wave reduction: smem as float [wave][2][64 d][32 keys]
-    float* red = reinterpret_cast<float*>(smem) + wave * (2 * 64 * 32);
+    // lane = key, registers = d (runs of 4): 8-byte stores into the k and v column blocks of dqkv
+    bf16_t* krow_out = dqkv + (row0 + kg) * ld + (int64_t)H * HD + (int64_t)kvh * HD;
+    bf16_t* vrow_out = krow_out + (int64_t)KV * HD;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int d = db * 32 + rowmap(r, h);
-            red[d * 32 + (lane & 31)] = dk[db][r] * 0.125f;
-            red[64 * 32 + d * 32 + (lane & 31)] = dv[db][r];
-        }
-    __syncthreads();
-    // thread -> (which, key, 8-d chunk): 2 * 32 * 8 = 512 items over 256 threads
-    const float* all = reinterpret_cast<const float*>(smem);
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 vk, vv;
 #pragma unroll
-    for (int rnd = 0; rnd < 2; ++rnd) {
-        const int item = tid + rnd * 256;
-        const int which = item >> 8, key = (item >> 3) & 31, dc = item & 7;
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int idx = which * 64 * 32 + (dc * 8 + e) * 32 + key;
-            o[e] = (bf16_t)(all[idx] + all[idx + 2 * 64 * 32] + all[idx + 4 * 64 * 32] + all[idx + 6 * 64 * 32]);
+            for (int e = 0; e < 4; ++e) {
+                vk[e] = (bf16_t)(dk[db][4 * g + e] * 0.125f);
+                vv[e] = (bf16_t)dv[db][4 * g + e];
+            }
+            *reinterpret_cast<bf16x4*>(krow_out + db * 32 + 8 * g + 4 * h) = vk;
+            *reinterpret_cast<bf16x4*>(vrow_out + db * 32 + 8 * g + 4 * h) = vv;
         }
-        bf16_t* dst = dqkv + (row0 + key0 + key) * ld + (int64_t)H * HD + (int64_t)(which ? KV : 0) * HD + (int64_t)kvh * HD + dc * 8;
-        *reinterpret_cast<bf16x8*>(dst) = o;
-    }
 }
 
 }  // namespace
@@ -501,7 +499,7 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * n_kv * (seq / (32 * qpw)))), dim3(256), 0, st, (const bf16_t*)qkv,
                        ld, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(batch * n_kv * (seq / 32))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(batch * n_kv * (seq / 128))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
                        (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
     return SSI_OK;

@@ -34,9 +34,9 @@ def init_distributed(device: torch.device, timeout_s: int = 600) -> tuple[int, i
         return 1, 0
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if device.type == "cuda" else "gloo"
+        backend = os.environ.get("SSI_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
         kwargs = {}
-        if device.type == "cuda":
+        if device.type == "cuda" and backend == "nccl":
             torch.cuda.set_device(device)
             kwargs["device_id"] = device
         dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s), **kwargs)

@@ -272,3 +272,57 @@ def test_bf16_mfma_shaped_model_matches_oracle_and_refreshes_transposed_weights(
     for name in ("emb", "L0.wqkv", "L1.w2"):
         assert torch.equal(model._view_t(name), model._view(name).t())
     assert l2.item() < loss.item()  # the step reduced the loss on the same batch
+
+
+def test_full_size_step_properties():
+    """BASELINE config A at full size (Llama-3.2-1B + 5000 DSUs, B=8, S=2048, bf16): size-independent properties.
+    (1) random-init loss ~ ln V; (2) bitwise reproducibility of loss and gradients; (3) gradient accumulation is additive;
+    (4) eval-mode loss == training loss; (5) token-type counts partition the batch."""
+    import copy
+    import math
+    from ssi.data import synthetic_batch
+    from ssi.llama_configs import configllama3_2_1b
+    from ssi.loss import CEWithChunkedOutputLoss, compute_loss
+    from ssi.model import HipLlamaDecoder
+    from ssi.train_utils import count_token_types, get_token_type_ranges
+    cfg = copy.deepcopy(configllama3_2_1b)
+    cfg.n_dsus, cfg.modality_tokens = 5000, True
+    model = HipLlamaDecoder(**cfg.parameters, dtype=torch.bfloat16, device=DEV, rope_cache_len=2048)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        model._flat.normal_(0.0, 0.02)
+        model._view("emb")[cfg.vocab_size:].zero_()
+        for p, name, _ in model._param_src:
+            if name.endswith("norm"):
+                p.fill_(1.0)
+    model.train()
+    loss_fn = CEWithChunkedOutputLoss()
+    b1 = _to_dev(synthetic_batch(8, 2048, 5000, index=0))
+    b2 = _to_dev(synthetic_batch(8, 2048, 5000, index=1))
+    ranges = get_token_type_ranges(cfg)
+    counts = count_token_types(b1["tokens"], ranges, 133_006)
+    assert sum(counts[k] for k in ranges) == 8 * 2048 and counts["total"] <= 8 * 2048 and counts["dsu"] > counts["text"]
+
+    def run(batch):
+        model.zero_grad()
+        loss = compute_loss(batch, model, loss_fn)
+        loss.backward()
+        return loss.item(), model._flat_grad.clone()
+
+    l1, g1 = run(b1)
+    assert abs(l1 - math.log(cfg.vocab_size)) < 1.0 and math.isfinite(l1)           # (1)
+    l1b, g1b = run(b1)
+    assert l1 == l1b and torch.equal(g1, g1b)                                        # (2)
+    l2, g2 = run(b2)
+    model.zero_grad()
+    compute_loss(b1, model, loss_fn).backward()
+    compute_loss(b2, model, loss_fn).backward()                                      # accumulates into the same buffer
+    acc = model._flat_grad.float()
+    ref = g1.float() + g2.float()
+    err = float((acc - ref).norm() / ref.norm())
+    assert err < 5e-3, err                                                           # (3) up to bf16 accumulation rounding
+    assert float(model._view("emb", None, model._flat_grad)[cfg.vocab_size:].abs().max()) == 0.0  # pad rows stay zero
+    model.eval()
+    with torch.inference_mode():
+        le = compute_loss(b1, model, loss_fn).item()
+    assert abs(le - l1) <= 1e-6 * abs(l1)                                            # (4)
