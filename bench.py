@@ -77,20 +77,41 @@ class GemmTimer:
         return tot_ms, tot_fl, per
 
 
+def usable_cores() -> int:
+    """CPU cores this process may really use (affinity mask and cgroup quota, not the host's total)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(seed: int) -> dict:
     """CPU oracle (pure torch, fp32) timed on this host: config P of BASELINE.json (B=2, S=512, V=133 258, full 16-layer
     1B model), one optimizer step = forward + backward + AdamW.  Bounded sample: 1 step (1024 tokens)."""
     from oracle import step_oracle
-    from oracle.llama_oracle import OracleCEWithChunkedOutputLoss, build_oracle
+    from oracle.llama_oracle import OracleCEWithChunkedOutputLoss, OracleLlama
     from ssi.data import synthetic_batch
     from ssi.llama_configs import configllama3_2_1b
     import copy
-    cores = os.cpu_count() or 1
+    cores = min(usable_cores(), 32)
     torch.set_num_threads(cores)
     cfg = copy.deepcopy(configllama3_2_1b)
     cfg.n_dsus, cfg.modality_tokens = 5000, True
     t0 = time.perf_counter()
-    model = build_oracle(cfg.parameters, dtype=torch.float32, seed=None, rope_cache_len=512)
+    print(f"[cpu_baseline] building the fp32 CPU oracle on {cores} threads ...", file=sys.stderr, flush=True)
+    with torch.device("meta"):
+        model = OracleLlama(**cfg.parameters, rope_cache_len=512)
+    rope = model.rope.clone()  # built on the host inside the constructor
+    model = model.to_empty(device="cpu")
+    model.rope = rope
     with torch.no_grad():
         for name, p in model.named_parameters():
             if name.endswith("scale"):
@@ -102,8 +123,10 @@ def cpu_baseline(seed: int) -> dict:
     opt = torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
     batch = synthetic_batch(2, 512, 5000, seed=seed)
     t_build = time.perf_counter() - t0
+    print(f"[cpu_baseline] built in {t_build:.1f} s; timing one optimizer step (B=2, S=512) ...", file=sys.stderr, flush=True)
     t1 = time.perf_counter()
     lb, n = step_oracle.train_step(model, loss_fn, batch)
+    print(f"[cpu_baseline] forward+backward {time.perf_counter() - t1:.1f} s", file=sys.stderr, flush=True)
     step_oracle.optimizer_step(model, opt, n)
     dt = time.perf_counter() - t1
     tokens = batch["tokens"].numel()
@@ -243,7 +266,7 @@ def main() -> int:
             try:
                 out["cpu_baseline"] = cpu_baseline(42_831)
             except Exception as e:  # the GPU number must still be reported
-                out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+                out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": usable_cores(), "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

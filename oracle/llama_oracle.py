@@ -169,9 +169,11 @@ class OracleLlama(nn.Module):
         self.norm = RMSNorm(embed_dim, norm_eps)
         self.num_output_chunks = 0
         self.max_seq_len = max_seq_len
-        theta = llama3_scaled_theta(embed_dim // num_heads, rope_base, scale_factor)
-        # the real model caches max_seq_len (131072) positions; tests may cap the table, values are identical
-        self.register_buffer("rope", rope_cache(theta, rope_cache_len or max_seq_len), persistent=False)
+        with torch.device("cpu"):  # host arithmetic even when the module is built under a meta-device context
+            theta = llama3_scaled_theta(embed_dim // num_heads, rope_base, scale_factor)
+            # the real model caches max_seq_len (131072) positions; tests may cap the table, values are identical
+            table = rope_cache(theta, rope_cache_len or max_seq_len)
+        self.register_buffer("rope", table, persistent=False)
 
     def set_num_output_chunks(self, n: int) -> None:
         self.num_output_chunks = n
