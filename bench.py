@@ -255,7 +255,7 @@ def main() -> int:
             tot_ms, tot_fl, per = timer.summary()
             names = {0: "NT", 1: "NN", 2: "TN"}
             out["roofline"] = {
-                "bound": "mfma", "kernel": "gemm_mfma_kernel<A_COL,B_COL,GLDS> (NT/NN/TN launches of the timed region)",
+                "bound": "mfma", "kernel": "gemm_mfma_kernel<A_COL,B_COL,false> (every non-split-K ssi_gemm launch of the timed region)",
                 "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
                 "launches": len(timer.records), "avg_launch_ms": tot_ms / len(timer.records),
