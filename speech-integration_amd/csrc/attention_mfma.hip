@@ -14,6 +14,7 @@
 // Workgroup = 4 waves; the waves of a workgroup share one kv head (K/V tiles staged once for the 4 query heads of a GQA
 // group).  No atomics anywhere: dQ gets its own pass (recomputing S and dP) so every output has exactly one writer and
 // results are bitwise reproducible.
+#include <type_traits>
 #include "common.cuh"
 
 namespace {
@@ -359,14 +360,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const int key0 = kgrp * 128 + wave * 32;
     const int kg = key0 + (lane & 31);
 
-    // K (pre-scaled by 2^-3) and V as B operands: lane holds row key0 + (l & 31), d = 16 ks + 8 h + j
+    // -K * 2^-3 and -V as B operands (lane holds row key0 + (l & 31), d = 16 ks + 8 h + j).  With the operands negated and
+    // +lse / +delta as the initial accumulators, the chains deliver  lse - S  and  delta - dP,  so that
+    // P = exp2(-(lse - S) log2 e) needs one multiply (by a negative constant) and -dS = P (delta - dP) one more: no
+    // subtractions, no zero-initialisation.  dK accumulates with the opposite sign and is flipped by the final scale.
     bf16x8 kf[4], vf[4];
     {
         const bf16_t* krow = qkv + (row0 + kg) * ld + (int64_t)H * HD + (int64_t)kvh * HD + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            kf[ks] = scale_frag(*reinterpret_cast<const bf16x8*>(krow + 16 * ks), 0.125f);
-            vf[ks] = *reinterpret_cast<const bf16x8*>(krow + (int64_t)KV * HD + 16 * ks);
+            kf[ks] = scale_frag(*reinterpret_cast<const bf16x8*>(krow + 16 * ks), -0.125f);
+            vf[ks] = scale_frag(*reinterpret_cast<const bf16x8*>(krow + (int64_t)KV * HD + 16 * ks), -1.0f);
         }
     }
     f32x16 dk[2], dv[2];
@@ -396,57 +400,64 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)rc,
                                          (__attribute__((address_space(3))) void*)(buf + 8192), 4, 0, 0);
     };
-    issue(0);
-    if (n_steps > 1) issue(1);
-    for (int step = 0; step < n_steps; ++step) {
+    // one step on ring buffer BUF (compile-time, so every LDS address is a hoisted per-lane base + an immediate)
+    auto do_step = [&](int step, auto buf_c) {
+        constexpr int BUF = decltype(buf_c)::value;
         const int q0 = (qb_first + step % per_head) * 32;
-        const char* qt = smem + (step % 3) * SB;
+        const char* qt = smem + BUF * SB;
         const char* dt = qt + 4096;
         const float* rcs = reinterpret_cast<const float*>(qt + 8192);
-        const bool active = q0 + 31 >= key0;  // wave-uniform: some query of the tile sees some key of this wave
         // own requests of this step have landed (the next step's 3 may stay in flight) ...
         if (step + 1 < n_steps) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // ... and everybody else's; the buffer of step-1 is free again
         if (step + 2 < n_steps) issue(step + 2);
-        f32x4 l4[4], d4[4];
-        if (active) {  // row constants of the accumulator rows (queries q0 + rowmap(r, h)), runs of 4
+        if (q0 + 31 < key0) return;  // wave-uniform: every key of this wave is in the future of every query of the tile
+        f32x16 sacc, pacc;  // rows = queries q0 + rowmap(r, h): row constants come in runs of 4
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                l4[g] = *reinterpret_cast<const f32x4*>(rcs + 4 * h + 8 * g);
-                d4[g] = *reinterpret_cast<const f32x4*>(rcs + 32 + 4 * h + 8 * g);
-            }
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(rcs + 4 * h + 8 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(rcs + 32 + 4 * h + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sacc[4 * g + e] = l4[e]; pacc[4 * g + e] = d4[e]; }
         }
-        if (active) {
-            // the row constants ride in as the initial accumulators: S' = Q K^T - lse, dP' = dO V^T - delta
-            f32x16 sacc, pacc;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { sacc[4 * g + e] = -l4[g][e]; pacc[4 * g + e] = -d4[g][e]; }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(qt, 0, ks, lane), kf[ks], sacc, 0, 0, 0);
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(dt, 0, ks, lane), vf[ks], pacc, 0, 0, 0);
-            }
-            const bool diag = q0 < key0 + 32;
+        for (int ks = 0; ks < 4; ++ks) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(qt, 0, ks, lane), kf[ks], sacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(dt, 0, ks, lane), vf[ks], pacc, 0, 0, 0);
+        }
+        if (q0 < key0 + 32) {  // diagonal tile: keys beyond the query contribute nothing
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(sacc[r] * LOG2E);
-                if (diag && kg > q0 + rowmap(r, h)) p = 0.f;
+                float p = __builtin_amdgcn_exp2f(sacc[r] * -LOG2E);
+                if (kg > q0 + rowmap(r, h)) p = 0.f;
                 sacc[r] = p;
                 pacc[r] *= p;
             }
+        } else {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 pf = acc_frag(sacc, s), dsf = acc_frag(pacc, s);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(dt, s * 16, db * 32, lane), pf, dv[db], 0, 0, 0);
-                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(qt, s * 16, db * 32, lane), dsf, dk[db], 0, 0, 0);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sacc[r] * -LOG2E);
+                sacc[r] = p;
+                pacc[r] *= p;
             }
         }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = acc_frag(sacc, s2), dsf = acc_frag(pacc, s2);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(dt, s2 * 16, db * 32, lane), pf, dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(qt, s2 * 16, db * 32, lane), dsf, dk[db], 0, 0, 0);
+            }
+        }
+    };
+    issue(0);
+    if (n_steps > 1) issue(1);
+    for (int step = 0; step < n_steps; step += 3) {
+        do_step(step, std::integral_constant<int, 0>{});
+        if (step + 1 < n_steps) do_step(step + 1, std::integral_constant<int, 1>{});
+        if (step + 2 < n_steps) do_step(step + 2, std::integral_constant<int, 2>{});
     }
     // lane = key, registers = d (runs of 4): 8-byte stores into the k and v column blocks of dqkv
     bf16_t* krow_out = dqkv + (row0 + kg) * ld + (int64_t)H * HD + (int64_t)kvh * HD;
@@ -458,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
             bf16x4 vk, vv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                vk[e] = (bf16_t)(dk[db][4 * g + e] * 0.125f);
+                vk[e] = (bf16_t)(dk[db][4 * g + e] * -0.125f);  // dk holds -sum dS Q
                 vv[e] = (bf16_t)dv[db][4 * g + e];
             }
             *reinterpret_cast<bf16x4*>(krow_out + db * 32 + 8 * g + 4 * h) = vk;
