@@ -129,8 +129,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     sk.store<SWZ_ROW>(smem, tid);
     sv.store<SWZ_TR>(smem + 8192, tid);
     __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        const char* kt = smem + (t & 1) * 16384;
+    auto tile_step = [&](int t, auto buf_c) {
+        constexpr int BUF = decltype(buf_c)::value;  // compile-time ring slot: LDS addresses = hoisted lane base + immediate
+        const char* kt = smem + BUF * 16384;
         const char* vt = kt + 8192;
         if (t + 1 < nt) {
             sk.load(kbase + (int64_t)(t + 1) * 64 * ld, ld, tid);
@@ -187,11 +188,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
             }
         }
         if (t + 1 < nt) {
-            char* nk = smem + ((t + 1) & 1) * 16384;
+            char* nk = smem + (BUF ^ 1) * 16384;
             sk.store<SWZ_ROW>(nk, tid);
             sv.store<SWZ_TR>(nk + 8192, tid);
         }
         __syncthreads();
+    };
+    for (int t = 0; t < nt; t += 2) {
+        tile_step(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nt) tile_step(t + 1, std::integral_constant<int, 1>{});
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.f / ltot;
@@ -296,15 +301,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                     pacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(vt, kb * 32, ks, lane), dof[ks], pacc[kb], 0, 0, 0);
                 }
             }
-            const bool diag = k0 + 63 > q0;
+            if (k0 + 63 > q0) {  // diagonal tile: keys beyond the query contribute nothing
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float p = __builtin_amdgcn_exp2f(sacc[kb][r] * LOG2E);
-                    if (diag && k0 + kb * 32 + rowmap(r, h) > qg) p = 0.f;
-                    sacc[kb][r] = p * pacc[kb][r];  // dS^T (the 1/sqrt(d) factor is applied once at the end)
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        float p = __builtin_amdgcn_exp2f(sacc[kb][r] * LOG2E);
+                        if (k0 + kb * 32 + rowmap(r, h) > qg) p = 0.f;
+                        sacc[kb][r] = p * pacc[kb][r];  // dS^T (the 1/sqrt(d) factor is applied once at the end)
+                    }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[kb][r] = __builtin_amdgcn_exp2f(sacc[kb][r] * LOG2E) * pacc[kb][r];
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bf16x8 dsf = acc_frag(sacc[s >> 1], s & 1);
