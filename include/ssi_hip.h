@@ -102,6 +102,16 @@ int ssi_gemm_splitk(int layout, int64_t M, int64_t N, int64_t K, const void* A, 
                     void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev, int accumulate, int dtype,
                     int splits, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Fused SwiGLU GEMMs (torchtune FeedForward and its autograd): the elementwise stage rides in the GEMM epilogue on the MFMA
+ * path (bf16, M % 256 == 0, I % 256 == 0, K % 64 == 0); otherwise the unfused kernels run.  Same rounding points either way.
+ *   fwd: GU[M, 2I] = X[M, K] W13[2I, K]^T  (W13 = [gate rows | up rows]),  ACT[M, I] = silu(gate) * up
+ *   bwd: DGU[M, 2I] = swiglu_backward(DY[M, K] W2, GU);  W2 as [I, K] (layout SSI_GEMM_NT) or [K, I] (SSI_GEMM_NN);
+ *        dact_ws: [M, I] scratch used only by the unfused fallback. */
+int ssi_gemm_swiglu_fwd(int64_t M, int64_t inter, int64_t K, const void* X, int64_t ldx, const void* W13, int64_t ldw, void* GU,
+                        int64_t ldgu, void* ACT, int64_t ldact, int dtype, void* stream);
+int ssi_gemm_swiglu_bwd(int layout, int64_t M, int64_t inter, int64_t K, const void* DY, int64_t lddy, const void* W2, int64_t ldw,
+                        const void* GU, int64_t ldgu, void* DGU, int64_t lddgu, void* dact_ws, int dtype, void* stream);
+
 /* dst[c][r] = src[r][c] for a [rows, cols] matrix (both dims multiples of 8).  Keeps [in, out] copies of the projection
  * weights so that the data-gradient GEMMs use the k-contiguous operand form (refreshed once per optimizer step). */
 int ssi_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols, int dtype,

@@ -137,3 +137,36 @@ extern "C" int ssi_gemm_splitk(int layout, int64_t M, int64_t N, int64_t K, cons
     return ssi_gemm_mfma_bf16_splitk(layout, M, N, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, accumulate, splits,
                                      (float*)workspace, stream);
 }
+
+// ---- fused SwiGLU GEMMs (K7 of SURVEY.md §2.3: FeedForward w2(silu(w1 x) * w3 x) and its backward) -------------------------
+bool ssi_gemm_swiglu_supported(int64_t M, int64_t inter, int64_t K, const void* p0, const void* p1, const void* p2, const void* p3,
+                               int64_t ld0, int64_t ld1, int64_t ld2, int64_t ld3);
+int ssi_gemm_swiglu_fwd_mfma(int64_t M, int64_t inter, int64_t K, const void* X, int64_t ldx, const void* W13, int64_t ldw,
+                             void* GU, int64_t ldgu, void* ACT, int64_t ldact, void* stream);
+int ssi_gemm_swiglu_bwd_mfma(int64_t M, int64_t inter, int64_t K, const void* DY, int64_t lddy, const void* W2T, int64_t ldw,
+                             const void* GU, int64_t ldgu, void* DGU, int64_t lddgu, void* stream);
+
+extern "C" int ssi_gemm_swiglu_fwd(int64_t M, int64_t inter, int64_t K, const void* X, int64_t ldx, const void* W13, int64_t ldw,
+                                   void* GU, int64_t ldgu, void* ACT, int64_t ldact, int dtype, void* stream) {
+    SSI_CHECK_ARG(X && W13 && GU && ACT && M >= 0 && inter > 0 && K > 0 && ldgu >= 2 * inter && ldact >= inter);
+    if (dtype == SSI_BF16 && g_impl != SSI_IMPL_GENERIC && ssi_gemm_swiglu_supported(M, inter, K, X, W13, GU, ACT, ldx, ldw, ldgu, ldact))
+        return ssi_gemm_swiglu_fwd_mfma(M, inter, K, X, ldx, W13, ldw, GU, ldgu, ACT, ldact, stream);
+    if (int rc = ssi_gemm(SSI_GEMM_NT, M, 2 * inter, K, X, ldx, W13, ldw, GU, ldgu, nullptr, 1.f, nullptr, 0, dtype, stream)) return rc;
+    SSI_CHECK_ARG(ldgu == 2 * inter && ldact == inter);
+    return ssi_swiglu_fwd(GU, ACT, M, inter, dtype, stream);
+}
+
+// d gu = swiglu_backward(DY * W2, GU).  W2 is given as [I, K] ("transposed copy", layout NT) or as [K, I] (layout NN).
+// Unfused fallback needs `dact_ws` ([M, I] scratch, may be NULL only when the fused path is taken).
+extern "C" int ssi_gemm_swiglu_bwd(int layout, int64_t M, int64_t inter, int64_t K, const void* DY, int64_t lddy, const void* W2,
+                                   int64_t ldw, const void* GU, int64_t ldgu, void* DGU, int64_t lddgu, void* dact_ws, int dtype,
+                                   void* stream) {
+    SSI_CHECK_ARG(DY && W2 && GU && DGU && M >= 0 && inter > 0 && K > 0 && ldgu >= 2 * inter && lddgu >= 2 * inter);
+    SSI_CHECK_ARG(layout == SSI_GEMM_NT || layout == SSI_GEMM_NN);
+    if (layout == SSI_GEMM_NT && dtype == SSI_BF16 && g_impl != SSI_IMPL_GENERIC &&
+        ssi_gemm_swiglu_supported(M, inter, K, DY, W2, GU, DGU, lddy, ldw, ldgu, lddgu))
+        return ssi_gemm_swiglu_bwd_mfma(M, inter, K, DY, lddy, W2, ldw, GU, ldgu, DGU, lddgu, stream);
+    SSI_CHECK_ARG(dact_ws != nullptr && ldgu == 2 * inter && lddgu == 2 * inter);
+    if (int rc = ssi_gemm(layout, M, inter, K, DY, lddy, W2, ldw, dact_ws, inter, nullptr, 1.f, nullptr, 0, dtype, stream)) return rc;
+    return ssi_swiglu_bwd(dact_ws, GU, DGU, M, inter, dtype, stream);
+}

@@ -43,14 +43,16 @@ __device__ __forceinline__ int col_swz(int krow) { return ((krow & 3) | (((krow 
 // ROW: rows r0..r0+255 of a [*, ld] matrix, k columns k0..k0+63.  COL: k-rows k0..k0+63, columns c0..c0+255.
 template <bool COL>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, int64_t r0, int64_t k0, char* lds_tile,
-                                           int tid) {
+                                           int tid, int64_t split_rows = 0) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const bf16_t* src;
         if (!COL) {
             const int row = p * 64 + (tid >> 3);
             const int chunk = (tid & 7) ^ ((row >> 1) & 7);
-            src = g + (r0 + row) * ld + k0 + chunk * 8;
+            // split_rows = I: tile rows 0..127 come from gate rows r0/2.., rows 128..255 from the matching up rows I + r0/2..
+            const int64_t grow = split_rows ? (row < 128 ? (r0 >> 1) + row : split_rows + (r0 >> 1) + row - 128) : r0 + row;
+            src = g + grow * ld + k0 + chunk * 8;
         } else {
             const int krow = p * 16 + (tid >> 5);
             const int chunk = (tid & 31) ^ col_swz(krow);
@@ -102,14 +104,26 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
 
 // SPLITK: blockIdx.y selects a contiguous range of K-tiles; the fp32 partial tile goes to slab[blockIdx.y] (an [M, N] fp32
 // matrix in the workspace) and splitk_reduce_kernel applies alpha / accumulate / residual and the bf16 rounding.
-template <bool A_COL, bool B_COL, bool SPLITK>
+// EPI: 0 plain epilogue; 1 SwiGLU forward (the 256 output columns of a tile are 128 gate + the matching 128 up columns of
+// W13; writes GU = [gate | up] and ACT = silu(gate) * up); 2 SwiGLU backward (C tile = d act, never stored: reads gate/up
+// from GU and writes d gate / d up into DGU).  Same rounding points as the separate swiglu kernels (bf16 GEMM result first).
+enum { EPI_PLAIN = 0, EPI_SWIGLU_FWD = 1, EPI_SWIGLU_BWD = 2 };
+struct EpiArgs {
+    bf16_t* out2;        // FWD: ACT [M, I]      BWD: DGU [M, 2I]
+    int64_t ld_out2;
+    const bf16_t* in2;   // BWD: GU [M, 2I]
+    int64_t ld_in2;
+    int64_t inter;       // I
+};
+
+template <bool A_COL, bool B_COL, bool SPLITK, int EPI = EPI_PLAIN>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int tiles_n, int64_t K,
                                                                const bf16_t* __restrict__ A, int64_t lda,
                                                                const bf16_t* __restrict__ B, int64_t ldb,
                                                                bf16_t* __restrict__ C, int64_t ldc,
                                                                const bf16_t* __restrict__ R, float alpha,
                                                                const float* __restrict__ alpha_dev, int accumulate,
-                                                               float* __restrict__ slabs) {
+                                                               float* __restrict__ slabs, EpiArgs ea) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
     auto tileB = [&](int buf) { return smem + buf * 2 * TILE_BYTES + TILE_BYTES; };
     auto stage = [&](int kt, int buf) {
         stage_tile<A_COL>(A, lda, m0, kofs + (int64_t)kt * BK, tileA(buf), tid);
-        stage_tile<B_COL>(B, ldb, n0, kofs + (int64_t)kt * BK, tileB(buf), tid);
+        stage_tile<B_COL>(B, ldb, n0, kofs + (int64_t)kt * BK, tileB(buf), tid, EPI == EPI_SWIGLU_FWD ? ea.inter : 0);
     };
     // Fragment registers: the wave's 128 x 64 tile is walked as 2 row halves (4 m-tiles each) x 2 k-halves per K-tile.
     // a0/a1 alternate between the row halves, b0/b1 between the k-halves; the ds_reads of the NEXT block are issued one
@@ -225,6 +239,64 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
             const int row = i * 16 + (lane & 15), col = j * 16 + (lane >> 4) * 4;
             *reinterpret_cast<bf16x4*>(ep + row * EPI_ROW_BYTES + col * 2) = v;
         }
+    if (EPI == EPI_SWIGLU_FWD) {
+        // tile columns 0..127 = gate (waves wn 0,1), 128..255 = the matching up columns (waves wn 2,3).  Each wave finishes 64
+        // rows of a (gate, up) pair of 64-column blocks: GU = [gate | up], ACT = silu(gate).to(bf16) * up
+        __syncthreads();
+        const int cb = wn & 1, half = wn >> 1;
+        const char* epg = smem + (wm * WAVES_N + cb) * EPI_WAVE_BYTES;
+        const char* epu = smem + (wm * WAVES_N + cb + 2) * EPI_WAVE_BYTES;
+        const int64_t g0 = (n0 >> 1) + cb * 64;  // gate column of this 64-column block
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = half * 64 + it * 8 + (lane >> 3), chunk = lane & 7;
+            const bf16x8 gv = *reinterpret_cast<const bf16x8*>(epg + row * EPI_ROW_BYTES + chunk * 16);
+            const bf16x8 uv = *reinterpret_cast<const bf16x8*>(epu + row * EPI_ROW_BYTES + chunk * 16);
+            bf16x8 av;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float gf = (float)gv[e];
+                const float sl = (float)(bf16_t)(gf / (1.f + expf(-gf)));
+                av[e] = (bf16_t)(sl * (float)uv[e]);
+            }
+            const int64_t grow = m0 + wm * WM + row;
+            *reinterpret_cast<bf16x8*>(C + grow * ldc + g0 + chunk * 8) = gv;
+            *reinterpret_cast<bf16x8*>(C + grow * ldc + ea.inter + g0 + chunk * 8) = uv;
+            *reinterpret_cast<bf16x8*>(ea.out2 + grow * ea.ld_out2 + g0 + chunk * 8) = av;
+        }
+        return;
+    }
+    if (EPI == EPI_SWIGLU_BWD) {
+        // the tile is d act [256 rows, 256 columns of I]: d gate = d act * up * silu'(gate), d up = d act * silu(gate)
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            bf16x8 gv[4], uv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = (blk * 4 + q) * 8 + (lane >> 3), chunk = lane & 7;
+                const bf16_t* gp = ea.in2 + (m0 + wm * WM + row) * ea.ld_in2 + n0 + wn * WN + chunk * 8;
+                gv[q] = *reinterpret_cast<const bf16x8*>(gp);
+                uv[q] = *reinterpret_cast<const bf16x8*>(gp + ea.inter);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = (blk * 4 + q) * 8 + (lane >> 3), chunk = lane & 7;
+                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(ep + row * EPI_ROW_BYTES + chunk * 16);
+                bf16x8 og, ou;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gf = (float)gv[q][e], df = (float)dv[e];
+                    const float sig = 1.f / (1.f + expf(-gf));
+                    ou[e] = (bf16_t)(df * (gf * sig));
+                    og[e] = (bf16_t)(df * (float)uv[q][e] * (sig * (1.f + gf * (1.f - sig))));
+                }
+                bf16_t* op = ea.out2 + (m0 + wm * WM + row) * ea.ld_out2 + n0 + wn * WN + chunk * 8;
+                *reinterpret_cast<bf16x8*>(op) = og;
+                *reinterpret_cast<bf16x8*>(op + ea.inter) = ou;
+            }
+        }
+        return;
+    }
     // each wave reads back only what it wrote: no workgroup barrier needed, the compiler's lgkmcnt wait orders it
 #pragma unroll
     for (int it = 0; it < WM / 8; ++it) {
@@ -294,11 +366,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *reinterpret_cast<bf16x8*>(C + off) = o;
 }
 
-template <bool A_COL, bool B_COL, bool SPLITK>
+template <bool A_COL, bool B_COL, bool SPLITK, int EPI = EPI_PLAIN>
 int launch(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
            int64_t ldc, const void* R, float alpha, const float* alpha_dev, int accumulate, hipStream_t st,
-           int splits = 1, float* slabs = nullptr) {
-    auto kern = gemm_mfma_kernel<A_COL, B_COL, SPLITK>;
+           int splits = 1, float* slabs = nullptr, EpiArgs ea = EpiArgs{nullptr, 0, nullptr, 0, 0}) {
+    auto kern = gemm_mfma_kernel<A_COL, B_COL, SPLITK, EPI>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -307,7 +379,7 @@ int launch(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, cons
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n), (unsigned)splits), dim3(NTHREADS), LDS_BYTES, st, tiles_m,
                        tiles_n, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (const bf16_t*)R, alpha,
-                       alpha_dev, accumulate, slabs);
+                       alpha_dev, accumulate, slabs, ea);
     SSI_LAUNCH_CHECK();
     if (SPLITK) {
         const int64_t M = (int64_t)tiles_m * BM, N = (int64_t)tiles_n * BN;
@@ -360,4 +432,29 @@ int ssi_gemm_mfma_bf16_splitk(int layout, int64_t M, int64_t N, int64_t K, const
     }
 #undef GO
     return SSI_ERR_ARG;
+}
+
+// ---- fused SwiGLU entries (MFMA path only; callers fall back to ssi_gemm + ssi_swiglu_* when this returns UNSUPPORTED) ----
+bool ssi_gemm_swiglu_supported(int64_t M, int64_t inter, int64_t K, const void* p0, const void* p1, const void* p2, const void* p3,
+                               int64_t ld0, int64_t ld1, int64_t ld2, int64_t ld3) {
+    if (M <= 0 || M % BM || inter % BN || K % BK) return false;
+    if ((ld0 | ld1 | ld2 | ld3) % 8) return false;
+    if (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2 | (uintptr_t)p3) & 15) return false;
+    return true;
+}
+
+int ssi_gemm_swiglu_fwd_mfma(int64_t M, int64_t inter, int64_t K, const void* X, int64_t ldx, const void* W13, int64_t ldw,
+                             void* GU, int64_t ldgu, void* ACT, int64_t ldact, void* stream) {
+    EpiArgs ea{(bf16_t*)ACT, ldact, nullptr, 0, inter};
+    // output tiles: 256 rows x (128 gate + 128 up) columns -> tiles_n = 2I / 256
+    return launch<false, false, false, EPI_SWIGLU_FWD>((int)(M / BM), (int)(2 * inter / BN), K, X, ldx, W13, ldw, GU, ldgu, nullptr, 1.f,
+                                                       nullptr, 0, (hipStream_t)stream, 1, nullptr, ea);
+}
+
+int ssi_gemm_swiglu_bwd_mfma(int64_t M, int64_t inter, int64_t K, const void* DY, int64_t lddy, const void* W2T, int64_t ldw,
+                             const void* GU, int64_t ldgu, void* DGU, int64_t lddgu, void* stream) {
+    EpiArgs ea{(bf16_t*)DGU, lddgu, (const bf16_t*)GU, ldgu, inter};
+    // d act [M, I] = DY [M, K] * W2T[I, K]^T; the tile never reaches memory
+    return launch<false, false, false, EPI_SWIGLU_BWD>((int)(M / BM), (int)(inter / BN), K, DY, lddy, W2T, ldw, DGU, lddgu, nullptr, 1.f,
+                                                       nullptr, 0, (hipStream_t)stream, 1, nullptr, ea);
 }

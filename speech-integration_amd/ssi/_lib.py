@@ -43,6 +43,9 @@ PROTOTYPES = {
     "ssi_gemm_splitk_workspace_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "ssi_gemm_splitk": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_float, _P,
                                 c_int, c_int, c_int, _P, c_int64, _P]),
+    "ssi_gemm_swiglu_fwd": (c_int, [c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int, _P]),
+    "ssi_gemm_swiglu_bwd": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int,
+                                    _P]),
     "ssi_transpose": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int, _P]),
     "ssi_ce_fwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, c_int, c_int, _P]),
     "ssi_ce_reduce": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),

@@ -328,9 +328,8 @@ class HipLlamaDecoder(nn.Module):
             rstd2 = A.get(f"rstd2.{sfx}", (T,), torch.float32)
             ops.rmsnorm_fwd(hmid, self._view(f"L{l}.mlp_norm"), xn2, rstd2, self.norm_eps)
             gu = A.get(f"gu.{sfx}", (T, 2 * I), dt)
-            ops.gemm(GEMM_NT, xn2, self._view(f"L{l}.w13"), gu)
             act = A.get(f"act.{sfx}", (T, I), dt)
-            ops.swiglu_fwd(gu, act)
+            ops.gemm_swiglu_fwd(xn2, self._view(f"L{l}.w13"), gu, act)  # SwiGLU rides in the GEMM epilogue
             hn_name = f"h{l + 1}" if save else f"hx{l & 1}"
             hnext = A.get(hn_name, (T, D), dt)
             ops.gemm(GEMM_NT, act, self._view(f"L{l}.w2"), hnext, residual=hmid)
@@ -389,11 +388,12 @@ class HipLlamaDecoder(nn.Module):
             hmid, gu, act = A.get(f"hmid.{l}", (T, D), dt), A.get(f"gu.{l}", (T, 2 * I), dt), A.get(f"act.{l}", (T, I), dt)
             h_in = A.get(f"h{l}", (T, D), dt)
             # MLP: h_out = hmid + act @ w2^T
-            dact = A.get("dact", (T, I), dt)
-            dgrad(dh, f"L{l}.w2", dact)
             wgrad(dh, act, f"L{l}.w2")
             dgu = A.get("dgu", (T, 2 * I), dt)
-            ops.swiglu_bwd(dact, gu, dgu)
+            if use_t:  # d act = dh W2 never reaches memory: the SwiGLU backward rides in the GEMM epilogue
+                ops.gemm_swiglu_bwd(GEMM_NT, dh, self._view_t(f"L{l}.w2"), gu, dgu, None)
+            else:
+                ops.gemm_swiglu_bwd(GEMM_NN, dh, self._view(f"L{l}.w2"), gu, dgu, A.get("dact", (T, I), dt))
             dxn = A.get("dxn", (T, D), dt)
             dgrad(dgu, f"L{l}.w13", dxn)
             wgrad(dgu, xn2, f"L{l}.w13")

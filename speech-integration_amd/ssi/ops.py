@@ -10,7 +10,7 @@ from . import _lib
 from ._lib import GEMM_NN, GEMM_NT, GEMM_TN, check, dtype_code, ptr, stream_ptr
 
 __all__ = ["embed_fwd", "embed_bwd", "rmsnorm_fwd", "rmsnorm_bwd", "rope_", "attn_fwd", "attn_bwd", "swiglu_fwd",
-           "swiglu_bwd", "gemm", "gemm_splitk", "splitk_choice", "transpose", "ce_fwd", "ce_reduce", "count_tokens", "scale_", "sumsq", "adamw_step", "set_impl",
+           "swiglu_bwd", "gemm", "gemm_splitk", "splitk_choice", "gemm_swiglu_fwd", "gemm_swiglu_bwd", "transpose", "ce_fwd", "ce_reduce", "count_tokens", "scale_", "sumsq", "adamw_step", "set_impl",
            "GEMM_NT", "GEMM_NN", "GEMM_TN"]
 
 
@@ -163,6 +163,27 @@ def gemm_splitk(layout: int, a: Tensor, b: Tensor, c: Tensor, splits: int, works
     check(_lib.load().ssi_gemm_splitk(layout, M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(c), c.stride(0), None,
                                       alpha, ptr(alpha_dev), int(accumulate), dtype_code(c.dtype), splits, ptr(workspace),
                                       workspace.numel() * workspace.element_size(), stream_ptr()), "ssi_gemm_splitk")
+
+
+def gemm_swiglu_fwd(x: Tensor, w13: Tensor, gu: Tensor, act: Tensor) -> None:
+    """gu = x @ w13^T ([gate | up]); act = silu(gate) * up — one launch on the MFMA path."""
+    M, K = x.shape
+    inter = act.shape[1]
+    assert w13.shape == (2 * inter, K) and gu.shape == (M, 2 * inter) and act.shape[0] == M
+    assert x.stride(1) == 1 and w13.stride(1) == 1 and gu.is_contiguous() and act.is_contiguous()
+    check(_lib.load().ssi_gemm_swiglu_fwd(M, inter, K, ptr(x), x.stride(0), ptr(w13), w13.stride(0), ptr(gu), gu.stride(0), ptr(act),
+                                          act.stride(0), dtype_code(x.dtype), stream_ptr()), "ssi_gemm_swiglu_fwd")
+
+
+def gemm_swiglu_bwd(layout: int, dy: Tensor, w2: Tensor, gu: Tensor, dgu: Tensor, dact_ws: Tensor | None) -> None:
+    """dgu = swiglu_backward(dy @ W2, gu); w2 is [I, K] for GEMM_NT (transposed copy) or [K, I] for GEMM_NN."""
+    M, K = dy.shape
+    inter = gu.shape[1] // 2
+    assert w2.shape == ((inter, K) if layout == GEMM_NT else (K, inter)) and dgu.shape == gu.shape and gu.shape[0] == M
+    assert dy.stride(1) == 1 and w2.stride(1) == 1 and gu.is_contiguous() and dgu.is_contiguous()
+    check(_lib.load().ssi_gemm_swiglu_bwd(layout, M, inter, K, ptr(dy), dy.stride(0), ptr(w2), w2.stride(0), ptr(gu), gu.stride(0),
+                                          ptr(dgu), dgu.stride(0), ptr(dact_ws), dtype_code(dy.dtype), stream_ptr()),
+          "ssi_gemm_swiglu_bwd")
 
 
 def transpose(src: Tensor, dst: Tensor) -> None:

@@ -413,3 +413,44 @@ def test_transpose(ops, dtype, rows, cols):
     dst = torch.empty(cols, rows, dtype=dtype, device=DEV)
     ops.transpose(src.to(DEV), dst)
     assert torch.equal(dst.cpu(), src.t().contiguous())  # bit-exact data movement
+
+
+def test_fused_swiglu_gemms_equal_the_unfused_kernels(ops):
+    """SwiGLU in the GEMM epilogue (MFMA path) must reproduce GEMM -> swiglu kernel bit for bit: same rounding points."""
+    from ssi import _lib
+    M, I, K = 512, 512, 256
+    x = rnd(M, K, dtype=torch.bfloat16, seed=40).to(DEV)
+    w13 = rnd(2 * I, K, dtype=torch.bfloat16, seed=41, scale=0.1).to(DEV)
+    w2t = rnd(I, K, dtype=torch.bfloat16, seed=42, scale=0.1).to(DEV)   # [I, K] = transposed copy of W2 [K, I]
+    dy = rnd(M, K, dtype=torch.bfloat16, seed=43).to(DEV)
+    # unfused reference through the same library
+    gu_ref = torch.empty(M, 2 * I, dtype=torch.bfloat16, device=DEV)
+    act_ref = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(ops.GEMM_NT, x, w13, gu_ref)
+    ops.swiglu_fwd(gu_ref, act_ref)
+    dact = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(ops.GEMM_NT, dy, w2t, dact)
+    dgu_ref = torch.empty_like(gu_ref)
+    ops.swiglu_bwd(dact, gu_ref, dgu_ref)
+    # fused
+    gu = torch.full_like(gu_ref, float("nan"))
+    act = torch.full_like(act_ref, float("nan"))
+    ops.gemm_swiglu_fwd(x, w13, gu, act)
+    assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+    dgu = torch.full_like(gu_ref, float("nan"))
+    ops.gemm_swiglu_bwd(ops.GEMM_NT, dy, w2t, gu_ref, dgu, None)
+    assert torch.equal(dgu, dgu_ref)
+    # against fp32 math on the CPU
+    xr, wr = x.float().cpu(), w13.float().cpu()
+    g = (xr @ wr.T).bfloat16().float()
+    ref_act = (F.silu(g[:, :I]).bfloat16().float() * g[:, I:]).bfloat16().float()
+    torch.testing.assert_close(act.float().cpu(), ref_act, rtol=2e-2, atol=2e-2)
+    # unfused fallback (generic implementation, NN layout with a scratch buffer) agrees within bf16 rounding
+    prev = ops.set_impl(_lib.IMPL_GENERIC)
+    try:
+        dgu2 = torch.empty_like(gu_ref)
+        ops.gemm_swiglu_bwd(ops.GEMM_NN, dy, w2t.t().contiguous(), gu_ref, dgu2, torch.empty(M, I, dtype=torch.bfloat16, device=DEV))
+        diff = (dgu2.float() - dgu_ref.float()).abs()
+        assert float(diff.max()) <= 2 ** -6 * float(dgu_ref.float().abs().max()) + 1e-3
+    finally:
+        ops.set_impl(prev)
