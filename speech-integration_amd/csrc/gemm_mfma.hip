@@ -41,6 +41,23 @@ __device__ __forceinline__ int col_swz(int krow) { return ((krow & 3) | (((krow 
 
 // ---- HBM -> LDS staging of one operand tile ------------------------------------------------------------------------
 // ROW: rows r0..r0+255 of a [*, ld] matrix, k columns k0..k0+63.  COL: k-rows k0..k0+63, columns c0..c0+255.
+// k-strided (COL) operand tiles of the weight-gradient form go global -> VGPR -> ds_write_b128: measured on this chip,
+// LDS-DMA writes in flight slow ds_read_b64_tr_b16 down (TN 1.05 -> 1.17 PFLOP/s with register staging), while plain
+// ds_read_b64/b128 are unaffected.
+__device__ __forceinline__ void stage_col_load(const bf16_t* __restrict__ g, int64_t ld, int64_t r0, int64_t k0, int tid,
+                                               u32x4 (&regs)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int krow = p * 16 + (tid >> 5);
+        const int chunk = (tid & 31) ^ col_swz(krow);
+        regs[p] = *reinterpret_cast<const u32x4*>(g + (k0 + krow) * ld + r0 + chunk * 8);
+    }
+}
+__device__ __forceinline__ void stage_col_write(char* lds_tile, int tid, const u32x4 (&regs)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(lds_tile + p * 8192 + tid * 16) = regs[p];
+}
+
 template <bool COL>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, int64_t r0, int64_t k0, char* lds_tile,
                                            int tid, int64_t split_rows = 0) {
@@ -149,6 +166,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
         stage_tile<A_COL>(A, lda, m0, kofs + (int64_t)kt * BK, tileA(buf), tid);
         stage_tile<B_COL>(B, ldb, n0, kofs + (int64_t)kt * BK, tileB(buf), tid, EPI == EPI_SWIGLU_FWD ? ea.inter : 0);
     };
+    if constexpr (A_COL && B_COL) {
+        // ---- weight-gradient form: both operands register-staged, one tile ahead; fragments of a whole k-half at once ----
+        u32x4 ra[4], rb[4];
+        stage_col_load(A, lda, m0, kofs, tid, ra);
+        stage_col_load(B, ldb, n0, kofs, tid, rb);
+        stage_col_write(tileA(0), tid, ra);
+        stage_col_write(tileB(0), tid, rb);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            __syncthreads();  // tile kt visible; every wave is done reading buffer cur^1
+            if (kt + 1 < nk) {
+                stage_col_load(A, lda, m0, kofs + (int64_t)(kt + 1) * BK, tid, ra);
+                stage_col_load(B, ldb, n0, kofs + (int64_t)(kt + 1) * BK, tid, rb);
+            }
+            const char* la = tileA(cur);
+            const char* lb = tileB(cur);
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                bf16x8 bfr[NT], afr[MT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bfr[j] = read_frag<true>(lb, wn * WN + j * 16, kh, lane);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) afr[i] = read_frag<true>(la, wm * WM + i * 16, kh, lane);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], afr[i], acc[j][i], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            if (kt + 1 < nk) {
+                stage_col_write(tileA(cur ^ 1), tid, ra);
+                stage_col_write(tileB(cur ^ 1), tid, rb);
+            }
+        }
+    } else {
     // Fragment registers: the wave's 128 x 64 tile is walked as 2 row halves (4 m-tiles each) x 2 k-halves per K-tile.
     // a0/a1 alternate between the row halves, b0/b1 between the k-halves; the ds_reads of the NEXT block are issued one
     // per MFMA of the current block (sched_group_barrier), so LDS reads stream continuously under the matrix pipe
@@ -211,6 +265,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
         mma(a1, b1, 1);
         INTERLEAVE(1);
         __builtin_amdgcn_sched_barrier(0);
+    }
+
     }
 
     // ---- epilogue: acc[j][i] holds C[m = wm*128 + i*16 + (lane&15)][n = wn*64 + j*16 + (lane>>4)*4 + r] ----------------
