@@ -85,13 +85,31 @@ template <int ROWS, int NTHR> struct TileStage {
     }
 };
 
+// K and V tile (64 keys x 64 d each, 8 KiB + 8 KiB) of step t into a ring slot by LDS-DMA: each of the 4 waves moves two
+// 1-KiB pieces (8 rows x 128 B) of K and two of V = 4 requests per wave per tile.  The bank swizzle of each image is
+// applied on the per-lane SOURCE address (the LDS image of an LDS-DMA instruction is lane-linear).
+template <int SWZ_K, int SWZ_V>
+__device__ __forceinline__ void dma_kv_tile(const bf16_t* kbase, const bf16_t* vbase, int64_t ld, int t, char* slot, int wave,
+                                            int lane) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int piece = p * 4 + wave;  // 8 pieces of 8 rows
+        const int row = piece * 8 + (lane >> 3);
+        const int64_t goff = ((int64_t)t * 64 + row) * ld;
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(kbase + goff + ((lane & 7) ^ swz<SWZ_K>(row)) * 8),
+                                         (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(vbase + goff + ((lane & 7) ^ swz<SWZ_V>(row)) * 8),
+                                         (__attribute__((address_space(3))) void*)(slot + 8192 + piece * 1024), 16, 0, 0);
+    }
+}
+
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
 // grid.x = B * KV * (S / (32 * QPW)),  QPW = 4 / rep q-blocks per workgroup; wave w: head kvh*rep + w % rep, q-block w / rep
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t ld, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, int S, int H, int KV) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];  // [buf][K|V][64][64] bf16
+    __shared__ __attribute__((aligned(16))) char smem[3 * 2 * 8192];  // ring of 3 x [K | V][64][64] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep = H / KV, qpw = 4 / rep;
     const int nqb = S / (32 * qpw);
@@ -123,20 +141,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     float m = -INFINITY, lsum = 0.f;  // running max (scaled-score units) and this half-wave's partial row sum
     const int qg = q0 + (lane & 31);
 
-    TileStage<64, 256> sk, sv;
-    sk.load(kbase, ld, tid);
-    sv.load(vbase, ld, tid);
-    sk.store<SWZ_ROW>(smem, tid);
-    sv.store<SWZ_TR>(smem + 8192, tid);
-    __syncthreads();
+    // ring of 3 tile slots filled by LDS-DMA two tiles ahead (4 requests per wave per tile)
+    dma_kv_tile<SWZ_ROW, SWZ_TR>(kbase, vbase, ld, 0, smem, wave, lane);
+    if (nt > 1) dma_kv_tile<SWZ_ROW, SWZ_TR>(kbase, vbase, ld, 1, smem + 16384, wave, lane);
     auto tile_step = [&](int t, auto buf_c) {
         constexpr int BUF = decltype(buf_c)::value;  // compile-time ring slot: LDS addresses = hoisted lane base + immediate
         const char* kt = smem + BUF * 16384;
         const char* vt = kt + 8192;
-        if (t + 1 < nt) {
-            sk.load(kbase + (int64_t)(t + 1) * 64 * ld, ld, tid);
-            sv.load(vbase + (int64_t)(t + 1) * 64 * ld, ld, tid);
-        }
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // own pieces of tile t landed (tile t+1 may fly)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // everybody's pieces landed; the slot of tile t-1 is free again
+        if (t + 2 < nt) dma_kv_tile<SWZ_ROW, SWZ_TR>(kbase, vbase, ld, t + 2, smem + ((BUF + 2) % 3) * 16384, wave, lane);
         const int k0 = t * 64;
         if (k0 <= q0 + 31) {  // wave-uniform: this tile intersects the causal range of the wave's rows
             f32x16 sacc[2];
@@ -187,16 +202,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_TR>(vt, s * 16, db * 32, lane), pf, oacc[db], 0, 0, 0);
             }
         }
-        if (t + 1 < nt) {
-            char* nk = smem + (BUF ^ 1) * 16384;
-            sk.store<SWZ_ROW>(nk, tid);
-            sv.store<SWZ_TR>(nk + 8192, tid);
-        }
-        __syncthreads();
     };
-    for (int t = 0; t < nt; t += 2) {
+    for (int t = 0; t < nt; t += 3) {
         tile_step(t, std::integral_constant<int, 0>{});
         if (t + 1 < nt) tile_step(t + 1, std::integral_constant<int, 1>{});
+        if (t + 2 < nt) tile_step(t + 2, std::integral_constant<int, 2>{});
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.f / ltot;
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S,
                                                           int H, int KV) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];
+    __shared__ __attribute__((aligned(16))) char smem[3 * 2 * 8192];  // ring of 3 x [K | V][64][64] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep = H / KV, qpw = 4 / rep;
     const int nqb = S / (32 * qpw);
@@ -275,19 +285,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
-    TileStage<64, 256> sk, sv;
-    sk.load(kbase, ld, tid);
-    sv.load(vbase, ld, tid);
-    sk.store<SWZ_ROW>(smem, tid);
-    sv.store<SWZ_ROW>(smem + 8192, tid);
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        const char* kt = smem + (t & 1) * 16384;
+    dma_kv_tile<SWZ_ROW, SWZ_ROW>(kbase, vbase, ld, 0, smem, wave, lane);
+    if (nt > 1) dma_kv_tile<SWZ_ROW, SWZ_ROW>(kbase, vbase, ld, 1, smem + 16384, wave, lane);
+    auto tile_step = [&](int t, auto buf_c) {
+        constexpr int BUF = decltype(buf_c)::value;
+        const char* kt = smem + BUF * 16384;
         const char* vt = kt + 8192;
-        if (t + 1 < nt) {
-            sk.load(kbase + (int64_t)(t + 1) * 64 * ld, ld, tid);
-            sv.load(vbase + (int64_t)(t + 1) * 64 * ld, ld, tid);
-        }
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // own pieces of tile t landed (tile t+1 may fly)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // everybody's pieces landed; the slot of tile t-1 is free again
+        if (t + 2 < nt) dma_kv_tile<SWZ_ROW, SWZ_ROW>(kbase, vbase, ld, t + 2, smem + ((BUF + 2) % 3) * 16384, wave, lane);
         const int k0 = t * 64;
         if (k0 <= q0 + 31) {
             f32x16 sacc[2], pacc[2];
@@ -324,12 +331,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                     dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(kt, s * 16, db * 32, lane), dsf, dq[db], 0, 0, 0);
             }
         }
-        if (t + 1 < nt) {
-            char* nk = smem + ((t + 1) & 1) * 16384;
-            sk.store<SWZ_ROW>(nk, tid);
-            sv.store<SWZ_ROW>(nk + 8192, tid);
-        }
-        __syncthreads();
+    };
+    for (int t = 0; t < nt; t += 3) {
+        tile_step(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nt) tile_step(t + 1, std::integral_constant<int, 1>{});
+        if (t + 2 < nt) tile_step(t + 2, std::integral_constant<int, 2>{});
     }
     bf16_t* drow = dqkv + (row0 + qg) * ld + (int64_t)head * HD;
 #pragma unroll
