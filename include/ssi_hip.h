@@ -36,7 +36,7 @@ enum { SSI_OK = 0, SSI_ERR_ARG = 1, SSI_ERR_UNSUPPORTED = 2, SSI_ERR_WORKSPACE =
 enum { SSI_GEMM_NT = 0, SSI_GEMM_NN = 1, SSI_GEMM_TN = 2 };
 /* which implementation ssi_gemm may use: AUTO picks the MFMA kernel when shape/dtype allow, else the generic one */
 enum { SSI_IMPL_AUTO = 0, SSI_IMPL_GENERIC = 1, SSI_IMPL_MFMA = 2,
-       SSI_IMPL_MFMA_REGSTAGE = 3 /* debug: MFMA GEMM with register staging instead of LDS-DMA */ };
+       SSI_IMPL_MFMA_WG8 = 3 /* debug / A-B runs: MFMA paths, but the NT GEMM restricted to the 8-wave LDS-DMA kernel */ };
 
 int ssi_abi_version(void);
 const char* ssi_last_error(void);

@@ -214,7 +214,7 @@ extern "C" int ssi_attn_fwd(const void* qkv, int64_t ld, void* out, float* lse, 
     SSI_CHECK_ARG(out && lse);
     if (batch * seq == 0) return SSI_OK;
     const bool fast = ssi_attn_mfma_supported(ld, batch, seq, n_heads, n_kv, head_dim, dtype);
-    if ((ssi_get_impl() == SSI_IMPL_MFMA || ssi_get_impl() == SSI_IMPL_MFMA_REGSTAGE) && !fast) { ssi_set_error("ssi_attn_fwd: MFMA path forced but unsupported shape"); return SSI_ERR_UNSUPPORTED; }
+    if ((ssi_get_impl() == SSI_IMPL_MFMA || ssi_get_impl() == SSI_IMPL_MFMA_WG8) && !fast) { ssi_set_error("ssi_attn_fwd: MFMA path forced but unsupported shape"); return SSI_ERR_UNSUPPORTED; }
     if (fast && ssi_get_impl() != SSI_IMPL_GENERIC) return ssi_attn_fwd_mfma(qkv, ld, out, lse, batch, seq, n_heads, n_kv, stream);
     const int64_t nw = batch * n_heads * seq;
     SSI_DISPATCH_DTYPE(dtype, ATTN_HD_SWITCH(head_dim, hipLaunchKernelGGL((attn_fwd_generic<T, HD>), dim3((unsigned)ssi_cdiv(nw, 4)),
@@ -231,7 +231,7 @@ extern "C" int ssi_attn_bwd(const void* qkv, int64_t ld, const void* out, const 
     SSI_CHECK_ARG(out && dout && lse && dqkv && delta);
     if (batch * seq == 0) return SSI_OK;
     const bool fast = ssi_attn_mfma_supported(ld, batch, seq, n_heads, n_kv, head_dim, dtype);
-    if ((ssi_get_impl() == SSI_IMPL_MFMA || ssi_get_impl() == SSI_IMPL_MFMA_REGSTAGE) && !fast) { ssi_set_error("ssi_attn_bwd: MFMA path forced but unsupported shape"); return SSI_ERR_UNSUPPORTED; }
+    if ((ssi_get_impl() == SSI_IMPL_MFMA || ssi_get_impl() == SSI_IMPL_MFMA_WG8) && !fast) { ssi_set_error("ssi_attn_bwd: MFMA path forced but unsupported shape"); return SSI_ERR_UNSUPPORTED; }
     if (fast && ssi_get_impl() != SSI_IMPL_GENERIC)
         return ssi_attn_bwd_mfma(qkv, ld, out, dout, lse, dqkv, delta, batch, seq, n_heads, n_kv, stream);
     auto st = (hipStream_t)stream;

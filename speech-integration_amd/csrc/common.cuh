@@ -48,6 +48,17 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
 
+// logistic function used by every SwiGLU site (elementwise kernels and the fused GEMM epilogues must agree bit for bit).
+// bf16 storage: v_exp_f32 / v_rcp_f32 (about 1 ulp each, far below the bf16 rounding that follows); f32 storage: libm.
+template <typename T> __device__ __forceinline__ float ssi_sigmoid(float x);
+template <> __device__ __forceinline__ float ssi_sigmoid<float>(float x) { return 1.f / (1.f + expf(-x)); }
+template <> __device__ __forceinline__ float ssi_sigmoid<bf16_t>(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.44269504088896f));
+}
+template <typename T> __device__ __forceinline__ float ssi_silu(float x);
+template <> __device__ __forceinline__ float ssi_silu<float>(float x) { return x / (1.f + expf(-x)); }
+template <> __device__ __forceinline__ float ssi_silu<bf16_t>(float x) { return x * ssi_sigmoid<bf16_t>(x); }
+
 // 16-byte vector of storage elements: 4 floats or 8 bf16
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {

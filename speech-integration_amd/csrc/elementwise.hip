@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* __restrict__ g
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const float gf = g.get(i);
-            const float s = to_f32<T>(from_f32<T>(gf / (1.f + expf(-gf))));  // F.silu result rounded to storage type
+            const float s = to_f32<T>(from_f32<T>(ssi_silu<T>(gf)));  // F.silu result rounded to storage type
             o.set(i, s * u.get(i));
         }
         store16(act + row * inter + col, o);
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ d
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const float gf = g.get(i), df = d.get(i);
-            const float sig = 1.f / (1.f + expf(-gf));
+            const float sig = ssi_sigmoid<T>(gf);
             const float silu = gf * sig;
             ou.set(i, df * silu);
             og.set(i, df * u.get(i) * (sig * (1.f + gf * (1.f - sig))));

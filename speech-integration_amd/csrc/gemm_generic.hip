@@ -16,7 +16,7 @@ int ssi_gemm_mfma_bf16_splitk(int layout, int64_t M, int64_t N, int64_t K, const
 static int g_impl = SSI_IMPL_AUTO;
 extern "C" int ssi_set_impl(int impl) {
     const int prev = g_impl;
-    if (impl >= SSI_IMPL_AUTO && impl <= SSI_IMPL_MFMA_REGSTAGE) g_impl = impl;
+    if (impl >= SSI_IMPL_AUTO && impl <= SSI_IMPL_MFMA_WG8) g_impl = impl;
     return prev;
 }
 int ssi_get_impl() { return g_impl; }
@@ -100,7 +100,7 @@ extern "C" int ssi_gemm(int layout, int64_t M, int64_t N, int64_t K, const void*
     else                            { SSI_CHECK_ARG(lda >= M && ldb >= N); sam = 1;   sak = lda; sbk = ldb; sbn = 1; }
 
     const bool mfma_ok = dtype == SSI_BF16 && ssi_gemm_mfma_supported(layout, M, N, K, A, lda, B, ldb, C, ldc, R);
-    if ((g_impl == SSI_IMPL_MFMA || g_impl == SSI_IMPL_MFMA_REGSTAGE) && !mfma_ok) {
+    if ((g_impl == SSI_IMPL_MFMA || g_impl == SSI_IMPL_MFMA_WG8) && !mfma_ok) {
         ssi_set_error("ssi_gemm: MFMA path forced but shape/dtype unsupported (M=%lld N=%lld K=%lld dtype=%d)",
                       (long long)M, (long long)N, (long long)K, dtype);
         return SSI_ERR_UNSUPPORTED;

@@ -18,6 +18,7 @@
 //       the residual / previous C in the same pass (same rounding points as F.linear followed by `+`).
 // Workgroup -> tile map: XCD-aware (consecutive tiles of a group share A rows / B columns inside one XCD's L2).
 #include "common.cuh"
+#include <type_traits>
 
 int ssi_get_impl();
 
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float gf = (float)gv[e];
-                const float sl = (float)(bf16_t)(gf / (1.f + expf(-gf)));
+                const float sl = (float)(bf16_t)ssi_silu<bf16_t>(gf);
                 av[e] = (bf16_t)(sl * (float)uv[e]);
             }
             const int64_t grow = m0 + wm * WM + row;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float gf = (float)gv[q][e], df = (float)dv[e];
-                    const float sig = 1.f / (1.f + expf(-gf));
+                    const float sig = ssi_sigmoid<bf16_t>(gf);
                     ou[e] = (bf16_t)(df * (gf * sig));
                     og[e] = (bf16_t)(df * (float)uv[q][e] * (sig * (1.f + gf * (1.f - sig))));
                 }
@@ -446,6 +447,311 @@ int launch(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, cons
     return SSI_OK;
 }
 
+// =====================================================================================================================
+// NT4: the k-contiguous (NT) form as a persistent kernel with one wave per SIMD — the shape the chip's own library picks
+// for these sizes (256 x 256 x 64 tile, 4 waves), written for this step's epilogues.
+//   * 256 threads = 4 waves as 2 x 2, 128 x 128 outputs per wave: all 256 AGPRs hold accumulators, LDS fragment traffic is
+//     2/3 of the 8-wave kernel's.  The MFMAs are inline asm with the accumulator tied in place: with the whole AGPR file in
+//     use the builtin form makes the allocator rotate accumulators through copies (hundreds of v_accvgpr moves per K-tile).
+//   * gridDim.x (= CUs) workgroups walk the output tiles b, b + G, ...  The global -> VGPR -> LDS operand stream runs three
+//     K-steps ahead of the MFMAs through two alternating register sets (every load has two full K-steps to land) and does
+//     not stop at tile boundaries: a tile's first operands arrive while the previous tile is still being multiplied.
+//   * One K-step = 8 blocks of 16 MFMAs.  Four fragment slots (4 x 16 rows x 32 k each) rotate so that each block fetches
+//     just the one set the next block is missing; the ds_write / buffer_load of the staging stream are spread one per
+//     ~4 MFMAs (a slot carrying a ds_write_b128 costs ~35 cycles instead of 16, so they must not bunch up); one raw
+//     s_barrier per K-step.  Measured: 2390 cycles per K-step against 2048 of pure MFMA issue.
+//   * Epilogue straight from registers: two v_permlane16_swap per tile pair give each lane 8 consecutive bf16 columns
+//     (16-B stores, 64 B per row per instruction); no LDS, so the operand stream keeps running underneath it.
+// Requires K % 128 == 0 and not both `accumulate` and R; other NT calls use the 8-wave kernel above.
+// =====================================================================================================================
+constexpr int NT4_THREADS = 256;
+constexpr int NT4_WM = 128, NT4_WN = 128;
+constexpr unsigned BUF_RSRC_DW3 = 0x00020000u;  // raw buffer, 32-bit data format (gfx9 family)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, BUF_RSRC_DW3);
+}
+
+// PREV: 0 = C is overwritten, 1 = C += result (accumulate), 2 = C = R + result (residual)
+template <int EPI, int PREV>
+__global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, int tiles_n, int64_t K, const bf16_t* __restrict__ A,
+                                                                  int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                                  bf16_t* __restrict__ C, int64_t ldc, const bf16_t* __restrict__ R,
+                                                                  float alpha, const float* __restrict__ alpha_dev, EpiArgs ea) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = tiles_m * tiles_n, G = (int)gridDim.x;
+    const int nk = (int)(K / BK);  // even
+
+    f32x4 acc[8][8];  // [j (n-tile)][i (m-tile)], defined by the zero-C MFMAs of each tile's first K-step
+    auto tileA = [&](int buf) { return smem + buf * 2 * TILE_BYTES; };
+    auto tileB = [&](int buf) { return smem + buf * 2 * TILE_BYTES + TILE_BYTES; };
+
+    // ---- load side: (lv, lkt) = output tile and K-tile of the next fetch ------------------------------------------------
+    int lv = (int)blockIdx.x, lkt = 0;
+    const bf16_t* baseA = A;
+    const bf16_t* baseB = B;
+    auto set_load_tile = [&](int v) {
+        int tm, tn;
+        tile_coords(v, tiles_m, tiles_n, tm, tn);
+        baseA = A + (int64_t)tm * BM * lda;
+        // SwiGLU forward: the 256 tile columns are [gate 0..63 | up 0..63 | gate 64..127 | up 64..127] of 128 W13 column pairs
+        baseB = B + (int64_t)tn * (EPI == EPI_SWIGLU_FWD ? BN / 2 : BN) * ldb;
+    };
+    auto advance = [&]() {
+        if (++lkt == nk) {
+            lkt = 0;
+            lv += G;
+            if (lv < ntiles) set_load_tile(lv);  // past the last tile: keep re-fetching valid memory, never consumed
+        }
+    };
+    // staging piece p of a tile = rows p*32 + (tid >> 3), 16-B chunk (tid & 7): one VGPR byte offset per operand, the
+    // (piece, K-tile) part rides in the scalar offset of the buffer load
+    const int offA = (int)(((tid >> 3) * lda + (tid & 7) * 8) * 2), offB = (int)(((tid >> 3) * ldb + (tid & 7) * 8) * 2);
+    auto pieceA = [&](int p) { return (int)(p * 32 * lda * 2); };
+    auto pieceB = [&](int p) {
+        if (EPI == EPI_SWIGLU_FWD) {
+            const int blk64 = p >> 1;  // 64-row block of the tile: 0 gate lo, 1 up lo, 2 gate hi, 3 up hi
+            return (int)((((blk64 & 1) ? ea.inter : 0) + (blk64 >> 1) * 64 + (p & 1) * 32) * ldb * 2);
+        }
+        return (int)(p * 32 * ldb * 2);
+    };
+    const int st_ofs = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) * 16);  // ROW-tile swizzle, same for every piece
+    auto gloadA = [&](u32x4& dst, int p) { dst = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(baseA), offA, pieceA(p) + lkt * (BK * 2), 0); };
+    auto gloadB = [&](u32x4& dst, int p) { dst = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(baseB), offB, pieceB(p) + lkt * (BK * 2), 0); };
+    auto lwrite1 = [&](char* tile, int p, const u32x4& v) { *reinterpret_cast<u32x4*>(tile + st_ofs + p * 4096) = v; };
+
+    bf16x8 S0[4], S1[4], S2[4], S3[4];  // fragment slots; roles rotate through one K-step (see body)
+    auto rdA1 = [&](bf16x8& dst, const char* la, int half, int kh, int i) { dst = read_frag<false>(la, wm * NT4_WM + (half * 4 + i) * 16, kh, lane); };
+    auto rdB1 = [&](bf16x8& dst, const char* lb, int half, int kh, int j) { dst = read_frag<false>(lb, wn * NT4_WN + (half * 4 + j) * 16, kh, lane); };
+    // one block = 16 MFMAs (4 m-tiles of slot a x 4 n-tiles of slot b); extra(q) is issued right after MFMA q and pinned there.
+    // zero_c: the block is the first to touch its 16 accumulator tiles in this output tile (C operand = 0, no zero fill).
+    auto blk = [&](const bf16x8 (&a)[4], int ah, const bf16x8 (&b)[4], int bh, auto zero_c, auto extra) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = q >> 2, j = q & 3;
+            if (decltype(zero_c)::value)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[bh * 4 + j][ah * 4 + i]) : "v"(b[j]), "v"(a[i]));
+            else
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[bh * 4 + j][ah * 4 + i]) : "v"(b[j]), "v"(a[i]));
+            extra(q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using F_ = std::false_type;
+    // entry: S0 = A rows-lo k-lo, S1 = B cols-lo k-lo of this K-step (LDS buffer kt & 1); (xa, xb) hold the next K-step
+    auto body = [&](int kt, u32x4 (&xa)[8], u32x4 (&xb)[8], auto first) {
+        const int cur = kt & 1;
+        const char* la = tileA(cur);
+        const char* lb = tileB(cur);
+        char* na = tileA(cur ^ 1);
+        char* nb = tileB(cur ^ 1);
+        // staging piece pc (0..7 = A, 8..15 = B) of the next K-step: registers -> idle LDS buffer in block pc/3, slot
+        // 4 + 4*(pc%3); its register is refilled (K-step +3) two slots later
+        auto stg = [&](int b, int q) {
+            if (q < 4 || (q & 1)) return;
+            const int pc = b * 3 + ((q - 4) >> 2);
+            if (pc >= 16) return;
+            if ((q & 3) == 0) {
+                if (pc < 8) lwrite1(na, pc, xa[pc]); else lwrite1(nb, pc - 8, xb[pc - 8]);
+            } else {
+                if (pc < 8) gloadA(xa[pc], pc); else gloadB(xb[pc - 8], pc - 8);
+            }
+        };
+        blk(S0, 0, S1, 0, first, [&](int q) { if (q < 4) rdB1(S2[q], lb, 1, 0, q); else stg(0, q); });
+        blk(S0, 0, S2, 1, first, [&](int q) { if (q < 4) rdA1(S3[q], la, 1, 0, q); else stg(1, q); });
+        blk(S3, 1, S2, 1, first, [&](int q) { if (q < 4) rdA1(S0[q], la, 0, 1, q); else stg(2, q); });
+        blk(S3, 1, S1, 0, first, [&](int q) { if (q < 4) rdB1(S2[q], lb, 0, 1, q); else stg(3, q); });
+        blk(S0, 0, S2, 0, F_{}, [&](int q) { if (q < 4) rdB1(S1[q], lb, 1, 1, q); else stg(4, q); });
+        blk(S0, 0, S1, 1, F_{}, [&](int q) { if (q < 4) rdA1(S3[q], la, 1, 1, q); else stg(5, q); });
+        advance();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // next K-step visible; every wave has read all of this one
+        blk(S3, 1, S1, 1, F_{}, [&](int q) { if (q < 4) rdA1(S0[q], na, 0, 0, q); });
+        blk(S3, 1, S2, 0, F_{}, [&](int q) { if (q < 4) rdB1(S1[q], nb, 0, 0, q); });
+    };
+    u32x4 ra0[8], rb0[8], ra1[8], rb1[8];
+    auto fetch_step = [&](u32x4 (&xa)[8], u32x4 (&xb)[8]) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) gloadA(xa[p], p);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) gloadB(xb[p], p);
+        advance();
+    };
+    set_load_tile(lv);
+    fetch_step(ra0, rb0);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) lwrite1(tileA(0), p, ra0[p]);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) lwrite1(tileB(0), p, rb0[p]);
+    fetch_step(ra1, rb1);
+    fetch_step(ra0, rb0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { rdA1(S0[q], tileA(0), 0, 0, q); rdB1(S1[q], tileB(0), 0, 0, q); }
+
+    const float al = alpha * (alpha_dev ? *alpha_dev : 1.f);
+    const int g = lane >> 4;
+    for (int v = (int)blockIdx.x; v < ntiles; v += G) {
+        int tm, tn;
+        tile_coords(v, tiles_m, tiles_n, tm, tn);
+        body(0, ra1, rb1, std::true_type{});
+        body(1, ra0, rb0, F_{});
+        for (int kt = 2; kt < nk; kt += 2) {
+            body(kt, ra1, rb1, F_{});
+            body(kt + 1, ra0, rb0, F_{});
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the asm MFMAs are opaque to the hazard recogniser: let the last results land
+        // ---- epilogue: acc[j][i] holds C[m = wm*128 + i*16 + (lane&15)][n = wn*128 + j*16 + (lane>>4)*4 + r] -------------
+        // pair(i, ja, jb): tiles ja, jb of m-tile i -> after the swaps lane (r, g) owns 8 consecutive columns of ONE of them:
+        // even 16-lane groups tile ja, odd groups tile jb, columns (g >> 1) * 8 .. + 7 of that tile
+        auto pair = [&](int i, int ja, int jb) {
+            bf16x4 x, y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float fx, fy;  // explicit reads, in program order: left to the allocator these become long-range AGPR shuffles
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(fx) : "a"(acc[ja][i][r]));
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(fy) : "a"(acc[jb][i][r]));
+                x[r] = (bf16_t)(fx * al);
+                y[r] = (bf16_t)(fy * al);
+            }
+            const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
+            const auto s0 = __builtin_amdgcn_permlane16_swap(xu[0], yu[0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(xu[1], yu[1], false, false);
+            u32x4 o;
+            o[0] = s0[0]; o[1] = s1[0]; o[2] = s0[1]; o[3] = s1[1];
+            return o;
+        };
+        const int64_t row0 = (int64_t)tm * BM + wm * NT4_WM;
+        const int lane_col = (g & 1) * 16 + (g >> 1) * 8;  // within a 32-column tile pair
+        if constexpr (EPI == EPI_PLAIN) {
+            const int64_t tile_off = row0 * ldc + (int64_t)tn * BN + wn * NT4_WN;
+            const __amdgpu_buffer_rsrc_t rsC = make_rsrc(C + tile_off);
+            const __amdgpu_buffer_rsrc_t rsP = make_rsrc(PREV == 2 ? R + tile_off : C + tile_off);
+            const int voff = (int)(((lane & 15) * ldc + lane_col) * 2);
+            auto soff = [&](int i, int jp) { return (int)((i * 16 * ldc + jp * 32) * 2); };
+            u32x4 pv[2][4];
+            auto ldprev = [&](int i) {
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) pv[i & 1][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsP, voff, soff(i, jp), 0);
+            };
+            if (PREV) ldprev(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (PREV && i + 1 < 8) ldprev(i + 1);
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    u32x4 o = pair(i, 2 * jp, 2 * jp + 1);
+                    if (PREV) {
+                        bf16x8 ob = __builtin_bit_cast(bf16x8, o);
+                        const bf16x8 c = __builtin_bit_cast(bf16x8, pv[i & 1][jp]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)((float)ob[e] + (float)c[e]);
+                        o = __builtin_bit_cast(u32x4, ob);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsC, voff, soff(i, jp), 0);
+                    __builtin_amdgcn_sched_barrier(0);  // one pair at a time: bounded register pressure
+                }
+            }
+        } else if constexpr (EPI == EPI_SWIGLU_FWD) {
+            // n-tiles 0..3 = gate columns c0 .. c0+63, n-tiles 4..7 = the matching up columns, c0 = tn*128 + wn*64:
+            // GU = [gate | up], ACT = silu(gate).to(bf16) * up   (same rounding points as ssi_swiglu_fwd)
+            const int64_t c0 = (int64_t)tn * (BN / 2) + wn * 64;
+            const __amdgpu_buffer_rsrc_t rsGU = make_rsrc(C + row0 * ldc + c0);
+            const __amdgpu_buffer_rsrc_t rsACT = make_rsrc(ea.out2 + row0 * ea.ld_out2 + c0);
+            const int voff = (int)(((lane & 15) * ldc + lane_col) * 2), voff2 = (int)(((lane & 15) * ea.ld_out2 + lane_col) * 2);
+            const int up_off = (int)(ea.inter * 2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const u32x4 og = pair(i, 2 * jp, 2 * jp + 1), ou = pair(i, 4 + 2 * jp, 5 + 2 * jp);
+                    const bf16x8 gv = __builtin_bit_cast(bf16x8, og), uv = __builtin_bit_cast(bf16x8, ou);
+                    bf16x8 av;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float sl = (float)(bf16_t)ssi_silu<bf16_t>((float)gv[e]);
+                        av[e] = (bf16_t)(sl * (float)uv[e]);
+                    }
+                    const int so = (int)((i * 16 * ldc + jp * 32) * 2), so2 = (int)((i * 16 * ea.ld_out2 + jp * 32) * 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(og, rsGU, voff, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ou, rsGU, voff, so + up_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, av), rsACT, voff2, so2, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        } else {
+            // SwiGLU backward: the tile is d act [256 rows, 256 columns of I], never stored: d gate = d act * up * silu'(gate),
+            // d up = d act * silu(gate), gate/up read from GU, written to DGU (same formulas as ssi_swiglu_bwd)
+            const int64_t c0 = (int64_t)tn * BN + wn * NT4_WN;
+            const __amdgpu_buffer_rsrc_t rsGU = make_rsrc(ea.in2 + row0 * ea.ld_in2 + c0);
+            const __amdgpu_buffer_rsrc_t rsDGU = make_rsrc(ea.out2 + row0 * ea.ld_out2 + c0);
+            const int voff = (int)(((lane & 15) * ea.ld_in2 + lane_col) * 2), voff2 = (int)(((lane & 15) * ea.ld_out2 + lane_col) * 2);
+            const int up_off = (int)(ea.inter * 2);
+            u32x4 pg[2][4], pu[2][4];
+            auto ldprev = [&](int i) {
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    const int so = (int)((i * 16 * ea.ld_in2 + jp * 32) * 2);
+                    pg[i & 1][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsGU, voff, so, 0);
+                    pu[i & 1][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsGU, voff, so + up_off, 0);
+                }
+            };
+            ldprev(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i + 1 < 8) ldprev(i + 1);
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    const bf16x8 dv = __builtin_bit_cast(bf16x8, pair(i, 2 * jp, 2 * jp + 1));
+                    const bf16x8 gv = __builtin_bit_cast(bf16x8, pg[i & 1][jp]), uv = __builtin_bit_cast(bf16x8, pu[i & 1][jp]);
+                    bf16x8 og, ou;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float gf = (float)gv[e], df = (float)dv[e];
+                        const float sig = ssi_sigmoid<bf16_t>(gf);
+                        ou[e] = (bf16_t)(df * (gf * sig));
+                        og[e] = (bf16_t)(df * (float)uv[e] * (sig * (1.f + gf * (1.f - sig))));
+                    }
+                    const int so2 = (int)((i * 16 * ea.ld_out2 + jp * 32) * 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, og), rsDGU, voff2, so2, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ou), rsDGU, voff2, so2 + up_off, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // the first fragments of the next tile (its K-step 0 sits in LDS buffer 0) are read again here rather than kept live
+        // across the epilogue
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { rdA1(S0[q], tileA(0), 0, 0, q); rdB1(S1[q], tileB(0), 0, 0, q); }
+    }
+}
+
+template <int EPI, int PREV>
+int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+               const void* R, float alpha, const float* alpha_dev, hipStream_t st, EpiArgs ea = EpiArgs{nullptr, 0, nullptr, 0, 0}) {
+    auto kern = gemm_nt4_kernel<EPI, PREV>;
+    static bool attr_set = false;  // per instantiation
+    static int num_cu = 256;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_BYTES);
+        if (e != hipSuccess) { ssi_set_error("gemm_nt4: cannot reserve %d B of LDS: %s", PIPE_BYTES, hipGetErrorString(e)); return SSI_ERR_HIP + (int)e; }
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            num_cu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    const int ntiles = tiles_m * tiles_n;
+    int grid = ntiles < num_cu ? ntiles : num_cu;
+    if (grid >= 8) grid &= ~7;  // whole XCD rounds keep the tile -> XCD map of tile_coords intact
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT4_THREADS), PIPE_BYTES, st, tiles_m, tiles_n, K, (const bf16_t*)A, lda,
+                       (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (const bf16_t*)R, alpha, alpha_dev, ea);
+    SSI_LAUNCH_CHECK();
+    return SSI_OK;
+}
+
+bool nt4_ok(int64_t K) { return K % (2 * BK) == 0 && ssi_get_impl() != SSI_IMPL_MFMA_WG8; }
 
 }  // namespace
 
@@ -467,7 +773,13 @@ int ssi_gemm_mfma_bf16(int layout, int64_t M, int64_t N, int64_t K, const void* 
     auto st = (hipStream_t)stream;
 #define GO(AC, BC) return launch<AC, BC, false>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, accumulate, st)
     switch (layout) {
-        case SSI_GEMM_NT: GO(false, false);
+        case SSI_GEMM_NT:
+            if (nt4_ok(K) && !(accumulate && R)) {
+                if (accumulate) return launch_nt4<EPI_PLAIN, 1>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (R) return launch_nt4<EPI_PLAIN, 2>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                return launch_nt4<EPI_PLAIN, 0>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+            }
+            GO(false, false);
         case SSI_GEMM_NN: GO(false, true);
         case SSI_GEMM_TN: GO(true, true);
     }
@@ -502,6 +814,9 @@ bool ssi_gemm_swiglu_supported(int64_t M, int64_t inter, int64_t K, const void* 
 int ssi_gemm_swiglu_fwd_mfma(int64_t M, int64_t inter, int64_t K, const void* X, int64_t ldx, const void* W13, int64_t ldw,
                              void* GU, int64_t ldgu, void* ACT, int64_t ldact, void* stream) {
     EpiArgs ea{(bf16_t*)ACT, ldact, nullptr, 0, inter};
+    if (nt4_ok(K))
+        return launch_nt4<EPI_SWIGLU_FWD, 0>((int)(M / BM), (int)(2 * inter / BN), K, X, ldx, W13, ldw, GU, ldgu, nullptr, 1.f, nullptr,
+                                             (hipStream_t)stream, ea);
     // output tiles: 256 rows x (128 gate + 128 up) columns -> tiles_n = 2I / 256
     return launch<false, false, false, EPI_SWIGLU_FWD>((int)(M / BM), (int)(2 * inter / BN), K, X, ldx, W13, ldw, GU, ldgu, nullptr, 1.f,
                                                        nullptr, 0, (hipStream_t)stream, 1, nullptr, ea);
@@ -510,6 +825,9 @@ int ssi_gemm_swiglu_fwd_mfma(int64_t M, int64_t inter, int64_t K, const void* X,
 int ssi_gemm_swiglu_bwd_mfma(int64_t M, int64_t inter, int64_t K, const void* DY, int64_t lddy, const void* W2T, int64_t ldw,
                              const void* GU, int64_t ldgu, void* DGU, int64_t lddgu, void* stream) {
     EpiArgs ea{(bf16_t*)DGU, lddgu, (const bf16_t*)GU, ldgu, inter};
+    if (nt4_ok(K))
+        return launch_nt4<EPI_SWIGLU_BWD, 0>((int)(M / BM), (int)(inter / BN), K, DY, lddy, W2T, ldw, DGU, lddgu, nullptr, 1.f, nullptr,
+                                             (hipStream_t)stream, ea);
     // d act [M, I] = DY [M, K] * W2T[I, K]^T; the tile never reaches memory
     return launch<false, false, false, EPI_SWIGLU_BWD>((int)(M / BM), (int)(inter / BN), K, DY, lddy, W2T, ldw, DGU, lddgu, nullptr, 1.f,
                                                        nullptr, 0, (hipStream_t)stream, 1, nullptr, ea);

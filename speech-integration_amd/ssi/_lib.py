@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("SSI_HIP_LIB") or os.path.join(os.path.dirname(_HERE),
 
 SSI_F32, SSI_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_MFMA_REGSTAGE = 0, 1, 2, 3
+IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_MFMA_WG8 = 0, 1, 2, 3
 ABI_VERSION = 1
 
 # name -> (restype, argtypes); mirrors include/ssi_hip.h line by line
