@@ -472,8 +472,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, BUF_RSRC_DW3);
 }
 
+// COL: false = both operands k-contiguous (NT), true = both k-strided (TN, the weight-gradient form: operand tiles are
+//      [64 k][256 columns] images read back with ds_read_b64_tr_b16, as in the 8-wave kernel)
 // PREV: 0 = C is overwritten, 1 = C += result (accumulate), 2 = C = R + result (residual)
-template <int EPI, int PREV>
+template <bool COL, int EPI, int PREV>
 __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, int tiles_n, int64_t K, const bf16_t* __restrict__ A,
                                                                   int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                                   bf16_t* __restrict__ C, int64_t ldc, const bf16_t* __restrict__ R,
@@ -486,8 +488,10 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     const int nk = (int)(K / BK);  // even
 
     f32x4 acc[8][8];  // [j (n-tile)][i (m-tile)], defined by the zero-C MFMAs of each tile's first K-step
-    auto tileA = [&](int buf) { return smem + buf * 2 * TILE_BYTES; };
-    auto tileB = [&](int buf) { return smem + buf * 2 * TILE_BYTES + TILE_BYTES; };
+    // LDS: [A buf 0 | A buf 1 | B buf 0 | B buf 1]; with the buffer index a compile-time constant every fragment address is one
+    // per-lane base register plus a 16-bit immediate
+    auto tileA = [&](int buf) { return smem + buf * TILE_BYTES; };
+    auto tileB = [&](int buf) { return smem + 2 * TILE_BYTES + buf * TILE_BYTES; };
 
     // ---- load side: (lv, lkt) = output tile and K-tile of the next fetch ------------------------------------------------
     int lv = (int)blockIdx.x, lkt = 0;
@@ -496,9 +500,14 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     auto set_load_tile = [&](int v) {
         int tm, tn;
         tile_coords(v, tiles_m, tiles_n, tm, tn);
-        baseA = A + (int64_t)tm * BM * lda;
-        // SwiGLU forward: the 256 tile columns are [gate 0..63 | up 0..63 | gate 64..127 | up 64..127] of 128 W13 column pairs
-        baseB = B + (int64_t)tn * (EPI == EPI_SWIGLU_FWD ? BN / 2 : BN) * ldb;
+        if (COL) {
+            baseA = A + (int64_t)tm * BM;
+            baseB = B + (int64_t)tn * BN;
+        } else {
+            baseA = A + (int64_t)tm * BM * lda;
+            // SwiGLU forward: the 256 tile columns are [gate 0..63 | up 0..63 | gate 64..127 | up 64..127] of 128 W13 column pairs
+            baseB = B + (int64_t)tn * (EPI == EPI_SWIGLU_FWD ? BN / 2 : BN) * ldb;
+        }
     };
     auto advance = [&]() {
         if (++lkt == nk) {
@@ -507,25 +516,59 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
             if (lv < ntiles) set_load_tile(lv);  // past the last tile: keep re-fetching valid memory, never consumed
         }
     };
-    // staging piece p of a tile = rows p*32 + (tid >> 3), 16-B chunk (tid & 7): one VGPR byte offset per operand, the
-    // (piece, K-tile) part rides in the scalar offset of the buffer load
-    const int offA = (int)(((tid >> 3) * lda + (tid & 7) * 8) * 2), offB = (int)(((tid >> 3) * ldb + (tid & 7) * 8) * 2);
-    auto pieceA = [&](int p) { return (int)(p * 32 * lda * 2); };
+    // staging, ROW tiles: piece p = rows p*32 + (tid >> 3), 16-B chunk (tid & 7), swizzled on the LDS side.  COL tiles: piece p =
+    // k-rows p*8 + (tid >> 5), chunk (tid & 31) swizzled on the SOURCE side (LDS image lane-linear); the swizzle term
+    // col_swz(k-row) only depends on p through its parity.  One VGPR byte offset per operand (two for COL); the (piece,
+    // K-tile) part rides in the scalar offset of the buffer load.
+    auto lane_off = [&](int64_t ld, int odd) {
+        if (COL) return (int)(((tid >> 5) * ld + (((tid & 31) ^ col_swz(odd * 8 + (tid >> 5))) * 8)) * 2);
+        return (int)(((tid >> 3) * ld + (tid & 7) * 8) * 2);
+    };
+    const int offA0 = lane_off(lda, 0), offA1 = COL ? lane_off(lda, 1) : offA0;
+    const int offB0 = lane_off(ldb, 0), offB1 = COL ? lane_off(ldb, 1) : offB0;
+    const int64_t kstepA = COL ? BK * lda : BK, kstepB = COL ? BK * ldb : BK;  // elements per K-step: added to the (64-bit) buffer base
+    auto pieceA = [&](int p) { return COL ? (int)(p * 8 * lda * 2) : (int)(p * 32 * lda * 2); };
     auto pieceB = [&](int p) {
+        if (COL) return (int)(p * 8 * ldb * 2);
         if (EPI == EPI_SWIGLU_FWD) {
             const int blk64 = p >> 1;  // 64-row block of the tile: 0 gate lo, 1 up lo, 2 gate hi, 3 up hi
             return (int)((((blk64 & 1) ? ea.inter : 0) + (blk64 >> 1) * 64 + (p & 1) * 32) * ldb * 2);
         }
         return (int)(p * 32 * ldb * 2);
     };
-    const int st_ofs = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) * 16);  // ROW-tile swizzle, same for every piece
-    auto gloadA = [&](u32x4& dst, int p) { dst = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(baseA), offA, pieceA(p) + lkt * (BK * 2), 0); };
-    auto gloadB = [&](u32x4& dst, int p) { dst = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(baseB), offB, pieceB(p) + lkt * (BK * 2), 0); };
+    const int st_ofs = COL ? tid * 16 : (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) * 16);
+    auto gloadA = [&](u32x4& dst, int p) { dst = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(baseA + lkt * kstepA), (p & 1) ? offA1 : offA0, pieceA(p), 0); };
+    auto gloadB = [&](u32x4& dst, int p) { dst = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(baseB + lkt * kstepB), (p & 1) ? offB1 : offB0, pieceB(p), 0); };
     auto lwrite1 = [&](char* tile, int p, const u32x4& v) { *reinterpret_cast<u32x4*>(tile + st_ofs + p * 4096) = v; };
 
     bf16x8 S0[4], S1[4], S2[4], S3[4];  // fragment slots; roles rotate through one K-step (see body)
-    auto rdA1 = [&](bf16x8& dst, const char* la, int half, int kh, int i) { dst = read_frag<false>(la, wm * NT4_WM + (half * 4 + i) * 16, kh, lane); };
-    auto rdB1 = [&](bf16x8& dst, const char* lb, int half, int kh, int j) { dst = read_frag<false>(lb, wn * NT4_WN + (half * 4 + j) * 16, kh, lane); };
+    // COL fragments: the address of 16-column group t (0..7) of a wave's operand is (group-0 address) XOR (t << 5) — the
+    // swizzle only touches the three chunk bits that t occupies — so one per-lane base per operand serves all 8 groups; the
+    // XOR is redone per read (kept from being hoisted into 16 live registers by the asm in body).
+    int trA = 0, trB = 0;
+    if (COL) {
+        const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, k0l = 8 * (lane >> 4) + q;
+        const int common = k0l * 512 + (pp >> 1) * 16 + 8 * (pp & 1) + (col_swz(k0l) << 4);
+        trA = common + wm * 256;
+        trB = common + wn * 256;
+    }
+    auto rd_tr = [&](const char* tile, int base, int t8, int kh) {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const char* a0 = tile + (base ^ (t8 << 5)) + kh * 16384;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 2048));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, r);
+    };
+    auto rdA1 = [&](bf16x8& dst, const char* la, int half, int kh, int i) {
+        if (COL) dst = rd_tr(la, trA, half * 4 + i, kh);
+        else dst = read_frag<false>(la, wm * NT4_WM + (half * 4 + i) * 16, kh, lane);
+    };
+    auto rdB1 = [&](bf16x8& dst, const char* lb, int half, int kh, int j) {
+        if (COL) dst = rd_tr(lb, trB, half * 4 + j, kh);
+        else dst = read_frag<false>(lb, wn * NT4_WN + (half * 4 + j) * 16, kh, lane);
+    };
     // one block = 16 MFMAs (4 m-tiles of slot a x 4 n-tiles of slot b); extra(q) is issued right after MFMA q and pinned there.
     // zero_c: the block is the first to touch its 16 accumulator tiles in this output tile (C operand = 0, no zero fill).
     auto blk = [&](const bf16x8 (&a)[4], int ah, const bf16x8 (&b)[4], int bh, auto zero_c, auto extra) {
@@ -541,9 +584,10 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
         }
     };
     using F_ = std::false_type;
-    // entry: S0 = A rows-lo k-lo, S1 = B cols-lo k-lo of this K-step (LDS buffer kt & 1); (xa, xb) hold the next K-step
-    auto body = [&](int kt, u32x4 (&xa)[8], u32x4 (&xb)[8], auto first) {
-        const int cur = kt & 1;
+    // entry: S0 = A rows-lo k-lo, S1 = B cols-lo k-lo of this K-step (LDS buffer cur = K-step parity); (xa, xb) hold the next K-step
+    auto body = [&](auto cur_c, u32x4 (&xa)[8], u32x4 (&xb)[8], auto first) {
+        constexpr int cur = decltype(cur_c)::value;
+        if (COL) asm volatile("" : "+v"(trA), "+v"(trB));
         const char* la = tileA(cur);
         const char* lb = tileB(cur);
         char* na = tileA(cur ^ 1);
@@ -596,11 +640,13 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     for (int v = (int)blockIdx.x; v < ntiles; v += G) {
         int tm, tn;
         tile_coords(v, tiles_m, tiles_n, tm, tn);
-        body(0, ra1, rb1, std::true_type{});
-        body(1, ra0, rb0, F_{});
+        using B0_ = std::integral_constant<int, 0>;
+        using B1_ = std::integral_constant<int, 1>;
+        body(B0_{}, ra1, rb1, std::true_type{});
+        body(B1_{}, ra0, rb0, F_{});
         for (int kt = 2; kt < nk; kt += 2) {
-            body(kt, ra1, rb1, F_{});
-            body(kt + 1, ra0, rb0, F_{});
+            body(B0_{}, ra1, rb1, F_{});
+            body(B1_{}, ra0, rb0, F_{});
         }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the asm MFMAs are opaque to the hazard recogniser: let the last results land
         // ---- epilogue: acc[j][i] holds C[m = wm*128 + i*16 + (lane&15)][n = wn*128 + j*16 + (lane>>4)*4 + r] -------------
@@ -727,10 +773,10 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     }
 }
 
-template <int EPI, int PREV>
+template <bool COL, int EPI, int PREV>
 int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                const void* R, float alpha, const float* alpha_dev, hipStream_t st, EpiArgs ea = EpiArgs{nullptr, 0, nullptr, 0, 0}) {
-    auto kern = gemm_nt4_kernel<EPI, PREV>;
+    auto kern = gemm_nt4_kernel<COL, EPI, PREV>;
     static bool attr_set = false;  // per instantiation
     static int num_cu = 256;
     if (!attr_set) {
@@ -752,6 +798,8 @@ int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, 
 }
 
 bool nt4_ok(int64_t K) { return K % (2 * BK) == 0 && ssi_get_impl() != SSI_IMPL_MFMA_WG8; }
+// buffer-load offsets are 32-bit: a tile's rows (k-contiguous) or one K-step's k-rows (k-strided) must stay within 2 GiB
+bool nt4_ld_ok(int64_t lda, int64_t ldb) { return 256 * lda * 2 < (1LL << 31) && 256 * ldb * 2 < (1LL << 31); }
 
 }  // namespace
 
@@ -774,14 +822,20 @@ int ssi_gemm_mfma_bf16(int layout, int64_t M, int64_t N, int64_t K, const void* 
 #define GO(AC, BC) return launch<AC, BC, false>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, accumulate, st)
     switch (layout) {
         case SSI_GEMM_NT:
-            if (nt4_ok(K) && !(accumulate && R)) {
-                if (accumulate) return launch_nt4<EPI_PLAIN, 1>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
-                if (R) return launch_nt4<EPI_PLAIN, 2>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
-                return launch_nt4<EPI_PLAIN, 0>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+            if (nt4_ok(K) && nt4_ld_ok(lda, ldb) && !(accumulate && R)) {
+                if (accumulate) return launch_nt4<false, EPI_PLAIN, 1>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (R) return launch_nt4<false, EPI_PLAIN, 2>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                return launch_nt4<false, EPI_PLAIN, 0>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
             }
             GO(false, false);
         case SSI_GEMM_NN: GO(false, true);
-        case SSI_GEMM_TN: GO(true, true);
+        case SSI_GEMM_TN:
+            if (nt4_ok(K) && nt4_ld_ok(lda, ldb) && !(accumulate && R)) {
+                if (accumulate) return launch_nt4<true, EPI_PLAIN, 1>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (R) return launch_nt4<true, EPI_PLAIN, 2>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                return launch_nt4<true, EPI_PLAIN, 0>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+            }
+            GO(true, true);
     }
 #undef GO
     return SSI_ERR_ARG;
@@ -815,7 +869,7 @@ int ssi_gemm_swiglu_fwd_mfma(int64_t M, int64_t inter, int64_t K, const void* X,
                              void* GU, int64_t ldgu, void* ACT, int64_t ldact, void* stream) {
     EpiArgs ea{(bf16_t*)ACT, ldact, nullptr, 0, inter};
     if (nt4_ok(K))
-        return launch_nt4<EPI_SWIGLU_FWD, 0>((int)(M / BM), (int)(2 * inter / BN), K, X, ldx, W13, ldw, GU, ldgu, nullptr, 1.f, nullptr,
+        return launch_nt4<false, EPI_SWIGLU_FWD, 0>((int)(M / BM), (int)(2 * inter / BN), K, X, ldx, W13, ldw, GU, ldgu, nullptr, 1.f, nullptr,
                                              (hipStream_t)stream, ea);
     // output tiles: 256 rows x (128 gate + 128 up) columns -> tiles_n = 2I / 256
     return launch<false, false, false, EPI_SWIGLU_FWD>((int)(M / BM), (int)(2 * inter / BN), K, X, ldx, W13, ldw, GU, ldgu, nullptr, 1.f,
@@ -826,7 +880,7 @@ int ssi_gemm_swiglu_bwd_mfma(int64_t M, int64_t inter, int64_t K, const void* DY
                              const void* GU, int64_t ldgu, void* DGU, int64_t lddgu, void* stream) {
     EpiArgs ea{(bf16_t*)DGU, lddgu, (const bf16_t*)GU, ldgu, inter};
     if (nt4_ok(K))
-        return launch_nt4<EPI_SWIGLU_BWD, 0>((int)(M / BM), (int)(inter / BN), K, DY, lddy, W2T, ldw, DGU, lddgu, nullptr, 1.f, nullptr,
+        return launch_nt4<false, EPI_SWIGLU_BWD, 0>((int)(M / BM), (int)(inter / BN), K, DY, lddy, W2T, ldw, DGU, lddgu, nullptr, 1.f, nullptr,
                                              (hipStream_t)stream, ea);
     // d act [M, I] = DY [M, K] * W2T[I, K]^T; the tile never reaches memory
     return launch<false, false, false, EPI_SWIGLU_BWD>((int)(M / BM), (int)(inter / BN), K, DY, lddy, W2T, ldw, DGU, lddgu, nullptr, 1.f,

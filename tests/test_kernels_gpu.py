@@ -289,6 +289,68 @@ def test_gemm_mfma_bf16(ops, impl_name, layout, M, N, K):
         ops.set_impl(prev)
 
 
+@pytest.mark.parametrize("layout", [0, 2])
+@pytest.mark.parametrize("mode", ["plain", "accumulate", "residual"])
+def test_gemm_persistent_kernel_walks_many_tiles(ops, layout, mode):
+    """4-wave persistent kernel (NT and TN forms): 512 output tiles on 256 CUs, so every workgroup runs its tile loop twice
+    and the operand stream crosses a tile boundary; exact on small integers and bit-identical to the 8-wave kernel."""
+    from ssi import _lib
+    M, N, K = 4096, 8192, 256
+    a, b = _gemm_operands(layout, M, N, K, torch.bfloat16, 61, integer=True)
+    a, b = a.to(DEV), b.to(DEV)
+    r = torch.randint(-3, 4, (M, N), generator=torch.Generator().manual_seed(62)).to(torch.bfloat16).to(DEV)
+    kw = {"accumulate": True, "alpha": 0.5} if mode == "accumulate" else ({"residual": r, "alpha": 0.25} if mode == "residual" else {})
+    outs = []
+    for impl in (_lib.IMPL_MFMA, _lib.IMPL_MFMA_WG8):
+        prev = ops.set_impl(impl)
+        try:
+            c = r.clone() if mode == "accumulate" else torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(layout, a, b, c, **kw)
+            outs.append(c)
+        finally:
+            ops.set_impl(prev)
+    assert torch.equal(outs[0], outs[1])
+    if mode == "plain":
+        ref = (a.float() @ b.float().t()) if layout == 0 else (a.float().t() @ b.float())
+        exact = ref.abs() <= 256
+        assert torch.equal(outs[0].float()[exact], ref[exact])
+    # random data, longer K: still bit-identical (same accumulation order in both kernels)
+    a, b = _gemm_operands(layout, 512, 768, 1024, torch.bfloat16, 63)
+    cs = []
+    for impl in (_lib.IMPL_MFMA, _lib.IMPL_MFMA_WG8):
+        prev = ops.set_impl(impl)
+        try:
+            c = torch.empty(512, 768, dtype=torch.bfloat16, device=DEV)
+            ops.gemm(layout, a.to(DEV), b.to(DEV), c)
+            cs.append(c)
+        finally:
+            ops.set_impl(prev)
+    assert torch.equal(cs[0], cs[1])
+
+
+def test_gemm_weight_gradient_form_beyond_2gib_of_k_offset(ops):
+    """TN form on a column window of a [K, ld] operand whose K extent spans more than 2 GiB (the LM-head weight gradient is
+    such a case): the K offset must not ride in a 32-bit buffer offset."""
+    from ssi import _lib
+    K, ld, M, N = 8192, 147_456, 512, 256
+    big = torch.empty(K, ld, dtype=torch.bfloat16, device=DEV)
+    big.normal_(generator=torch.Generator(device=DEV).manual_seed(64))
+    a = big[:, 1024:1024 + M]          # rows k, leading dimension ld: K * ld * 2 B = 2.4 GB
+    b = torch.randn(K, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(65)).bfloat16()
+    cs = []
+    for impl in (_lib.IMPL_MFMA, _lib.IMPL_MFMA_WG8):
+        prev = ops.set_impl(impl)
+        try:
+            c = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            ops.gemm(ops.GEMM_TN, a, b, c)
+            cs.append(c)
+        finally:
+            ops.set_impl(prev)
+    assert torch.equal(cs[0], cs[1])
+    ref = a.float().t() @ b.float()
+    torch.testing.assert_close(cs[0].float(), ref, rtol=2e-2, atol=0.03 * math.sqrt(K))
+
+
 def test_gemm_mfma_forced_on_bad_shape_fails_loudly(ops):
     from ssi import _lib
     prev = ops.set_impl(_lib.IMPL_MFMA)
