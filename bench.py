@@ -37,28 +37,69 @@ def flops_per_token(vocab: int, seq: int, dim: int = 2048, layers: int = 16) -> 
     return 3.0 * (2.0 * (N_LAYERS_MM + dim * vocab) + 2.0 * layers * dim * (seq + 1))
 
 
+class _HipEvents:
+    """HIP events created with hipEventDisableSystemFence, straight from libamdhip64: torch.cuda.Event's default record carries a
+    system-scope release (an L2 write-back after every timed launch), which slowed the step by 8 %; these do not."""
+
+    def __init__(self):
+        import ctypes
+        self.ct = ctypes
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+        self.hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+        self.pool = []
+
+    def record(self, stream_ptr):
+        ev = self.ct.c_void_p()
+        rc = self.hip.hipEventCreateWithFlags(self.ct.byref(ev), 0x20000000)  # hipEventDisableSystemFence
+        if rc != 0:
+            raise RuntimeError(f"hipEventCreateWithFlags failed: {rc}")
+        rc = self.hip.hipEventRecord(ev, self.ct.c_void_p(stream_ptr))
+        if rc != 0:
+            raise RuntimeError(f"hipEventRecord failed: {rc}")
+        self.pool.append(ev)
+        return ev
+
+    def elapsed_ms(self, a, b) -> float:
+        ms = self.ct.c_float()
+        rc = self.hip.hipEventElapsedTime(self.ct.byref(ms), a, b)
+        if rc != 0:
+            raise RuntimeError(f"hipEventElapsedTime failed: {rc}")
+        return float(ms.value)
+
+    def close(self):
+        for ev in self.pool:
+            self.hip.hipEventDestroy(ev)
+        self.pool = []
+
+
 class GemmTimer:
     """HIP-event timing of every ssi_gemm launch inside the timed region (events on the stream the kernels run on)."""
 
     def __init__(self):
-        self.records = []  # (layout, flops, start, end)
+        self.records = []  # ((layout, epilogue class), flops, start, end)
         self.enabled = False
+        self.ev = None
 
     def install(self):
         from ssi import ops
         inner = ops.gemm
         timer = self
+        self.ev = _HipEvents()
 
         def timed_gemm(layout, a, b, c, **kw):
             if not timer.enabled:
                 return inner(layout, a, b, c, **kw)
             M, N = c.shape
             K = a.shape[1] if layout in (ops.GEMM_NT, ops.GEMM_NN) else a.shape[0]
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
+            st = torch.cuda.current_stream().cuda_stream
+            s = timer.ev.record(st)
             inner(layout, a, b, c, **kw)
-            e.record()
-            timer.records.append((layout, 2.0 * M * N * K, s, e))
+            e = timer.ev.record(st)
+            prev = 1 if kw.get("accumulate") else (2 if kw.get("residual") is not None else 0)
+            timer.records.append(((layout, prev), 2.0 * M * N * K, s, e))
 
         ops.gemm = timed_gemm
         import ssi.model as m
@@ -66,14 +107,15 @@ class GemmTimer:
 
     def summary(self):
         tot_ms, tot_fl, per = 0.0, 0.0, {}
-        for layout, fl, s, e in self.records:
-            ms = s.elapsed_time(e)
+        for key, fl, s, e in self.records:
+            ms = self.ev.elapsed_ms(s, e)
             tot_ms += ms
             tot_fl += fl
-            d = per.setdefault(layout, [0, 0.0, 0.0])
+            d = per.setdefault(key, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += ms
             d[2] += fl
+        self.ev.close()
         return tot_ms, tot_fl, per
 
 
@@ -252,15 +294,21 @@ def main() -> int:
             out["mfma_roofline_frac_step"] = value * f_tok / (world * MFMA_PEAK_TFLOPS * 1e12)
             out["gflop_per_token"] = f_tok / 1e9
         if timer.records:
-            tot_ms, tot_fl, per = timer.summary()
-            names = {0: "NT", 1: "NN", 2: "TN"}
+            _, _, per = timer.summary()
+            # one kernel symbol per (layout, epilogue) class; the roofline object is the dominant one: the plain NT launches
+            # (QKV / output / LM-head projections and their data gradients) = gemm_nt4_kernel<false, 0, 0>
+            sym = {(0, 0): "gemm_nt4_kernel<false,0,0>", (0, 1): "gemm_nt4_kernel<false,0,1>", (0, 2): "gemm_nt4_kernel<false,0,2>",
+                   (2, 0): "gemm_nt4_kernel<true,0,0>", (2, 1): "gemm_nt4_kernel<true,0,1>", (2, 2): "gemm_nt4_kernel<true,0,2>"}
+            dom = max(per, key=lambda k: per[k][1])
+            n, ms, fl = per[dom]
             out["roofline"] = {
-                "bound": "mfma", "kernel": "gemm_mfma_kernel<A_COL,B_COL,false> (every non-split-K ssi_gemm launch of the timed region)",
-                "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
-                "launches": len(timer.records), "avg_launch_ms": tot_ms / len(timer.records),
-                "share_of_step_time": tot_ms / (1e3 * elapsed),
-                "per_layout": {names[k]: {"launches": v[0], "avg_ms": v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12} for k, v in per.items()},
+                "bound": "mfma", "kernel": sym.get(dom, f"gemm_mfma_kernel layout={dom[0]}"),
+                "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+                "launches": n, "avg_launch_ms": ms / n, "flop_per_launch_avg": fl / n,
+                "share_of_step_time": ms / (1e3 * elapsed),
+                "other_gemm_kernels": {sym.get(k, str(k)): {"launches": v[0], "avg_ms": v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
+                                       for k, v in per.items() if k != dom},
             }
         if world == 1 and not args.no_cpu_baseline:
             try:

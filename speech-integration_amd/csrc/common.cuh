@@ -58,6 +58,16 @@ template <> __device__ __forceinline__ float ssi_sigmoid<bf16_t>(float x) {
 template <typename T> __device__ __forceinline__ float ssi_silu(float x);
 template <> __device__ __forceinline__ float ssi_silu<float>(float x) { return x / (1.f + expf(-x)); }
 template <> __device__ __forceinline__ float ssi_silu<bf16_t>(float x) { return x * ssi_sigmoid<bf16_t>(x); }
+// SwiGLU backward per element, shared by ssi_swiglu_bwd and the fused GEMM epilogues: contraction is switched off here so
+// that every call site rounds identically whatever surrounds it (the fused and unfused paths are tested bit for bit).
+template <typename T> __device__ __forceinline__ void ssi_swiglu_bwd_elem(float gf, float uf, float df, float& dgate, float& dup) {
+#pragma clang fp contract(off)
+    const float sig = ssi_sigmoid<T>(gf);
+    const float one_minus = 1.f - sig;
+    const float t = 1.f + gf * one_minus;
+    dup = df * (gf * sig);
+    dgate = (df * uf) * (sig * t);
+}
 
 // 16-byte vector of storage elements: 4 floats or 8 bf16
 template <typename T> struct Vec16;

@@ -260,11 +260,10 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ d
         Vec16<T> d = load16(dact + row * inter + col), og, ou;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const float gf = g.get(i), df = d.get(i);
-            const float sig = ssi_sigmoid<T>(gf);
-            const float silu = gf * sig;
-            ou.set(i, df * silu);
-            og.set(i, df * u.get(i) * (sig * (1.f + gf * (1.f - sig))));
+            float dg, du;
+            ssi_swiglu_bwd_elem<T>(g.get(i), u.get(i), d.get(i), dg, du);
+            ou.set(i, du);
+            og.set(i, dg);
         }
         store16(dgu + row * 2 * inter + col, og);
         store16(dgu + row * 2 * inter + inter + col, ou);

@@ -342,10 +342,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
                 bf16x8 og, ou;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float gf = (float)gv[q][e], df = (float)dv[e];
-                    const float sig = ssi_sigmoid<bf16_t>(gf);
-                    ou[e] = (bf16_t)(df * (gf * sig));
-                    og[e] = (bf16_t)(df * (float)uv[q][e] * (sig * (1.f + gf * (1.f - sig))));
+                    float dg, du;
+                    ssi_swiglu_bwd_elem<bf16_t>((float)gv[q][e], (float)uv[q][e], (float)dv[e], dg, du);
+                    ou[e] = (bf16_t)du;
+                    og[e] = (bf16_t)dg;
                 }
                 bf16_t* op = ea.out2 + (m0 + wm * WM + row) * ea.ld_out2 + n0 + wn * WN + chunk * 8;
                 *reinterpret_cast<bf16x8*>(op) = og;
@@ -652,15 +652,15 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
         // ---- epilogue: acc[j][i] holds C[m = wm*128 + i*16 + (lane&15)][n = wn*128 + j*16 + (lane>>4)*4 + r] -------------
         // pair(i, ja, jb): tiles ja, jb of m-tile i -> after the swaps lane (r, g) owns 8 consecutive columns of ONE of them:
         // even 16-lane groups tile ja, odd groups tile jb, columns (g >> 1) * 8 .. + 7 of that tile
-        auto pair = [&](int i, int ja, int jb) {
+        auto pair = [&](int i, int ja, int jb, auto scale_c) {
             bf16x4 x, y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float fx, fy;  // explicit reads, in program order: left to the allocator these become long-range AGPR shuffles
                 asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(fx) : "a"(acc[ja][i][r]));
                 asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(fy) : "a"(acc[jb][i][r]));
-                x[r] = (bf16_t)(fx * al);
-                y[r] = (bf16_t)(fy * al);
+                x[r] = (bf16_t)(decltype(scale_c)::value ? fx * al : fx);
+                y[r] = (bf16_t)(decltype(scale_c)::value ? fy * al : fy);
             }
             const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
             const auto s0 = __builtin_amdgcn_permlane16_swap(xu[0], yu[0], false, false);
@@ -669,35 +669,53 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
             o[0] = s0[0]; o[1] = s1[0]; o[2] = s0[1]; o[3] = s1[1];
             return o;
         };
+        // duo(i, j0): the four tiles j0 .. j0+3 (64 columns = one 128-B line per row) of m-tile i as two 16-B vectors per lane
+        // arranged for FULL-LINE stores: a store whose 16-lane groups each cover 64 B of 16 different rows costs ~7x a store of
+        // whole 128-B lines (measured), so lanes 8..15 of every group trade rows with lanes 0..7 (two DPP row shifts):
+        //   lo: rows 0..7  — lanes r < 8 keep (row r, columns 0..31),  lanes r >= 8 take (row r-8, columns 32..63)
+        //   hi: rows 8..15 — lanes r < 8 take (row r+8, columns 0..31), lanes r >= 8 keep (row r, columns 32..63)
+        auto duo = [&](int i, int j0, auto scale_c, u32x4& lo, u32x4& hi) {
+            const u32x4 oa = pair(i, j0, j0 + 1, scale_c), ob = pair(i, j0 + 2, j0 + 3, scale_c);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                lo[d] = (unsigned)__builtin_amdgcn_update_dpp((int)oa[d], (int)ob[d], 0x118 /* row_shr:8 */, 0xF, 0xC, false);
+                hi[d] = (unsigned)__builtin_amdgcn_update_dpp((int)ob[d], (int)oa[d], 0x108 /* row_shl:8 */, 0xF, 0x3, false);
+            }
+        };
         const int64_t row0 = (int64_t)tm * BM + wm * NT4_WM;
-        const int lane_col = (g & 1) * 16 + (g >> 1) * 8;  // within a 32-column tile pair
+        // lane -> (row within an 8-row group, column within a 64-column duo)
+        const int lane_row = lane & 7, lane_col = ((lane >> 3) & 1) * 32 + (g & 1) * 16 + (g >> 1) * 8;
+        auto epilogue = [&](auto scale_c) {
         if constexpr (EPI == EPI_PLAIN) {
             const int64_t tile_off = row0 * ldc + (int64_t)tn * BN + wn * NT4_WN;
             const __amdgpu_buffer_rsrc_t rsC = make_rsrc(C + tile_off);
             const __amdgpu_buffer_rsrc_t rsP = make_rsrc(PREV == 2 ? R + tile_off : C + tile_off);
-            const int voff = (int)(((lane & 15) * ldc + lane_col) * 2);
-            auto soff = [&](int i, int jp) { return (int)((i * 16 * ldc + jp * 32) * 2); };
-            u32x4 pv[2][4];
+            const int voff = (int)((lane_row * ldc + lane_col) * 2);
+            auto soff = [&](int i, int h, int jd) { return (int)(((i * 16 + h * 8) * ldc + jd * 64) * 2); };
+            u32x4 pv[2][4];  // [m-tile parity][(duo, half)]
             auto ldprev = [&](int i) {
 #pragma unroll
-                for (int jp = 0; jp < 4; ++jp) pv[i & 1][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsP, voff, soff(i, jp), 0);
+                for (int q = 0; q < 4; ++q) pv[i & 1][q] = __builtin_amdgcn_raw_buffer_load_b128(rsP, voff, soff(i, q & 1, q >> 1), 0);
+            };
+            auto add_prev = [&](u32x4& o, const u32x4& p) {
+                bf16x8 ob = __builtin_bit_cast(bf16x8, o);
+                const bf16x8 c = __builtin_bit_cast(bf16x8, p);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)((float)ob[e] + (float)c[e]);
+                o = __builtin_bit_cast(u32x4, ob);
             };
             if (PREV) ldprev(0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if (PREV && i + 1 < 8) ldprev(i + 1);
 #pragma unroll
-                for (int jp = 0; jp < 4; ++jp) {
-                    u32x4 o = pair(i, 2 * jp, 2 * jp + 1);
-                    if (PREV) {
-                        bf16x8 ob = __builtin_bit_cast(bf16x8, o);
-                        const bf16x8 c = __builtin_bit_cast(bf16x8, pv[i & 1][jp]);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)((float)ob[e] + (float)c[e]);
-                        o = __builtin_bit_cast(u32x4, ob);
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rsC, voff, soff(i, jp), 0);
-                    __builtin_amdgcn_sched_barrier(0);  // one pair at a time: bounded register pressure
+                for (int jd = 0; jd < 2; ++jd) {
+                    u32x4 lo, hi;
+                    duo(i, jd * 4, scale_c, lo, hi);
+                    if (PREV) { add_prev(lo, pv[i & 1][jd * 2]); add_prev(hi, pv[i & 1][jd * 2 + 1]); }
+                    __builtin_amdgcn_raw_buffer_store_b128(lo, rsC, voff, soff(i, 0, jd), 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(hi, rsC, voff, soff(i, 1, jd), 0);
+                    __builtin_amdgcn_sched_barrier(0);  // one duo at a time: bounded register pressure
                 }
             }
         } else if constexpr (EPI == EPI_SWIGLU_FWD) {
@@ -706,66 +724,85 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
             const int64_t c0 = (int64_t)tn * (BN / 2) + wn * 64;
             const __amdgpu_buffer_rsrc_t rsGU = make_rsrc(C + row0 * ldc + c0);
             const __amdgpu_buffer_rsrc_t rsACT = make_rsrc(ea.out2 + row0 * ea.ld_out2 + c0);
-            const int voff = (int)(((lane & 15) * ldc + lane_col) * 2), voff2 = (int)(((lane & 15) * ea.ld_out2 + lane_col) * 2);
+            const int voff = (int)((lane_row * ldc + lane_col) * 2), voff2 = (int)((lane_row * ea.ld_out2 + lane_col) * 2);
             const int up_off = (int)(ea.inter * 2);
+            auto act_of = [&](const u32x4& gq, const u32x4& uq) {
+                const bf16x8 gv = __builtin_bit_cast(bf16x8, gq), uv = __builtin_bit_cast(bf16x8, uq);
+                bf16x8 av;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
-                    const u32x4 og = pair(i, 2 * jp, 2 * jp + 1), ou = pair(i, 4 + 2 * jp, 5 + 2 * jp);
-                    const bf16x8 gv = __builtin_bit_cast(bf16x8, og), uv = __builtin_bit_cast(bf16x8, ou);
-                    bf16x8 av;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float sl = (float)(bf16_t)ssi_silu<bf16_t>((float)gv[e]);
-                        av[e] = (bf16_t)(sl * (float)uv[e]);
-                    }
-                    const int so = (int)((i * 16 * ldc + jp * 32) * 2), so2 = (int)((i * 16 * ea.ld_out2 + jp * 32) * 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(og, rsGU, voff, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(ou, rsGU, voff, so + up_off, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, av), rsACT, voff2, so2, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int e = 0; e < 8; ++e) {
+                    const float sl = (float)(bf16_t)ssi_silu<bf16_t>((float)gv[e]);
+                    av[e] = (bf16_t)(sl * (float)uv[e]);
                 }
+                return __builtin_bit_cast(u32x4, av);
+            };
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                u32x4 glo, ghi, ulo, uhi;
+                duo(i, 0, scale_c, glo, ghi);
+                duo(i, 4, scale_c, ulo, uhi);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4& gq = h ? ghi : glo;
+                    const u32x4& uq = h ? uhi : ulo;
+                    const int so = (int)(((i * 16 + h * 8) * ldc) * 2), so2 = (int)(((i * 16 + h * 8) * ea.ld_out2) * 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(gq, rsGU, voff, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(uq, rsGU, voff, so + up_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(act_of(gq, uq), rsACT, voff2, so2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
             // SwiGLU backward: the tile is d act [256 rows, 256 columns of I], never stored: d gate = d act * up * silu'(gate),
             // d up = d act * silu(gate), gate/up read from GU, written to DGU (same formulas as ssi_swiglu_bwd)
             const int64_t c0 = (int64_t)tn * BN + wn * NT4_WN;
             const __amdgpu_buffer_rsrc_t rsGU = make_rsrc(ea.in2 + row0 * ea.ld_in2 + c0);
             const __amdgpu_buffer_rsrc_t rsDGU = make_rsrc(ea.out2 + row0 * ea.ld_out2 + c0);
-            const int voff = (int)(((lane & 15) * ea.ld_in2 + lane_col) * 2), voff2 = (int)(((lane & 15) * ea.ld_out2 + lane_col) * 2);
+            const int voff = (int)((lane_row * ea.ld_in2 + lane_col) * 2), voff2 = (int)((lane_row * ea.ld_out2 + lane_col) * 2);
             const int up_off = (int)(ea.inter * 2);
-            u32x4 pg[2][4], pu[2][4];
-            auto ldprev = [&](int i) {
+            u32x4 pg[2][2], pu[2][2];  // [unit parity][half]; unit = (m-tile i, duo jd), fetched one unit ahead
+            auto ldprev = [&](int u) {
 #pragma unroll
-                for (int jp = 0; jp < 4; ++jp) {
-                    const int so = (int)((i * 16 * ea.ld_in2 + jp * 32) * 2);
-                    pg[i & 1][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsGU, voff, so, 0);
-                    pu[i & 1][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsGU, voff, so + up_off, 0);
+                for (int h = 0; h < 2; ++h) {
+                    const int so = (int)((((u >> 1) * 16 + h * 8) * ea.ld_in2 + (u & 1) * 64) * 2);
+                    pg[u & 1][h] = __builtin_amdgcn_raw_buffer_load_b128(rsGU, voff, so, 0);
+                    pu[u & 1][h] = __builtin_amdgcn_raw_buffer_load_b128(rsGU, voff, so + up_off, 0);
                 }
+            };
+            auto grads = [&](const u32x4& dq, const u32x4& gq, const u32x4& uq, u32x4& og_out, u32x4& ou_out) {
+                const bf16x8 dv = __builtin_bit_cast(bf16x8, dq), gv = __builtin_bit_cast(bf16x8, gq), uv = __builtin_bit_cast(bf16x8, uq);
+                bf16x8 og, ou;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float dg, du;
+                    ssi_swiglu_bwd_elem<bf16_t>((float)gv[e], (float)uv[e], (float)dv[e], dg, du);
+                    ou[e] = (bf16_t)du;
+                    og[e] = (bf16_t)dg;
+                }
+                og_out = __builtin_bit_cast(u32x4, og);
+                ou_out = __builtin_bit_cast(u32x4, ou);
             };
             ldprev(0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i + 1 < 8) ldprev(i + 1);
+            for (int u = 0; u < 16; ++u) {
+                if (u + 1 < 16) ldprev(u + 1);
+                const int i = u >> 1, jd = u & 1;
+                u32x4 lo, hi;
+                duo(i, jd * 4, scale_c, lo, hi);
 #pragma unroll
-                for (int jp = 0; jp < 4; ++jp) {
-                    const bf16x8 dv = __builtin_bit_cast(bf16x8, pair(i, 2 * jp, 2 * jp + 1));
-                    const bf16x8 gv = __builtin_bit_cast(bf16x8, pg[i & 1][jp]), uv = __builtin_bit_cast(bf16x8, pu[i & 1][jp]);
-                    bf16x8 og, ou;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float gf = (float)gv[e], df = (float)dv[e];
-                        const float sig = ssi_sigmoid<bf16_t>(gf);
-                        ou[e] = (bf16_t)(df * (gf * sig));
-                        og[e] = (bf16_t)(df * (float)uv[e] * (sig * (1.f + gf * (1.f - sig))));
-                    }
-                    const int so2 = (int)((i * 16 * ea.ld_out2 + jp * 32) * 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, og), rsDGU, voff2, so2, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ou), rsDGU, voff2, so2 + up_off, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int h = 0; h < 2; ++h) {
+                    u32x4 og, ou;
+                    grads(h ? hi : lo, pg[u & 1][h], pu[u & 1][h], og, ou);
+                    const int so2 = (int)(((i * 16 + h * 8) * ea.ld_out2 + jd * 64) * 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(og, rsDGU, voff2, so2, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ou, rsDGU, voff2, so2 + up_off, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        };
+        if (al == 1.f) epilogue(std::false_type{});
+        else epilogue(std::true_type{});
         // the first fragments of the next tile (its K-step 0 sits in LDS buffer 0) are read again here rather than kept live
         // across the epilogue
 #pragma unroll
