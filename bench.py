@@ -119,6 +119,22 @@ class GemmTimer:
         return tot_ms, tot_fl, per
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_traffic.json, written by tools/pmc_traffic.py
+    from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None when no pass covers the kernel."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    best = None
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "*_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("bench_kernel") == kernel:
+            best = d.get("traffic_bytes_per_launch")
+    return best
+
+
 def usable_cores() -> int:
     """CPU cores this process may really use (affinity mask and cgroup quota, not the host's total)."""
     n = os.cpu_count() or 1
@@ -304,7 +320,7 @@ def main() -> int:
             out["roofline"] = {
                 "bound": "mfma", "kernel": sym.get(dom, f"gemm_mfma_kernel layout={dom[0]}"),
                 "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+                "frac": fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(sym.get(dom, "")),
                 "launches": n, "avg_launch_ms": ms / n, "flop_per_launch_avg": fl / n,
                 "share_of_step_time": ms / (1e3 * elapsed),
                 "other_gemm_kernels": {sym.get(k, str(k)): {"launches": v[0], "avg_ms": v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
