@@ -311,10 +311,10 @@ def main() -> int:
             out["gflop_per_token"] = f_tok / 1e9
         if timer.records:
             _, _, per = timer.summary()
-            # one kernel symbol per (layout, epilogue) class; the roofline object is the dominant one: the plain NT launches
-            # (QKV / output / LM-head projections and their data gradients) = gemm_nt4_kernel<false, 0, 0>
-            sym = {(0, 0): "gemm_nt4_kernel<false,0,0>", (0, 1): "gemm_nt4_kernel<false,0,1>", (0, 2): "gemm_nt4_kernel<false,0,2>",
-                   (2, 0): "gemm_nt4_kernel<true,0,0>", (2, 1): "gemm_nt4_kernel<true,0,1>", (2, 2): "gemm_nt4_kernel<true,0,2>"}
+            # one kernel symbol per (operand layout, epilogue) class: gemm_nt4_kernel<A_COL, B_COL, EPI_PLAIN, PREV>; the roofline
+            # object is the class with the largest share of the step
+            lay = {0: "false,false", 1: "false,true", 2: "true,true"}
+            sym = {(l, pv): f"gemm_nt4_kernel<{lay[l]},0,{pv}>" for l in lay for pv in (0, 1, 2)}
             dom = max(per, key=lambda k: per[k][1])
             n, ms, fl = per[dom]
             out["roofline"] = {

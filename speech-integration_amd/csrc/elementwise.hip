@@ -106,20 +106,32 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
         partials[(int64_t)blockIdx.x * dim + c0] = lds[c0] + lds[dim + c0] + lds[2 * dim + c0] + lds[3 * dim + c0];
 }
 
-// dscale[c] += sum_b partials[b][c]   (fixed order -> deterministic)
+// dscale[c] += sum_b partials[b][c]   (fixed order -> deterministic).  64 columns x 16 row groups per 1024-thread block: every
+// thread has nblocks/16 independent loads in flight (with 4 row groups the 128-deep dependent chain made this launch cost as
+// much as the 60x larger rmsnorm_bwd pass in front of it).
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_accum_kernel(const float* __restrict__ partials, T* __restrict__ dscale,
-                                                           int nblocks, int dim) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void colsum_accum_kernel(const float* __restrict__ partials, T* __restrict__ dscale,
+                                                            int nblocks, int dim) {
+    __shared__ float red[16][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cx;
     float s = 0.f;
-    if (col < dim)
-        for (int b = ry; b < nblocks; b += 4) s += partials[(int64_t)b * dim + col];
+    if (col < dim) {
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        int b = ry;
+        for (; b + 48 < nblocks; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) part[u] += partials[(int64_t)(b + 16 * u) * dim + col];
+        }
+        for (; b < nblocks; b += 16) part[0] += partials[(int64_t)b * dim + col];
+        s = (part[0] + part[1]) + (part[2] + part[3]);
+    }
     red[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && col < dim) {
-        const float t = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][cx];
         dscale[col] = from_f32<T>(to_f32<T>(dscale[col]) + t);
     }
 }
@@ -158,7 +170,7 @@ static int launch_rmsnorm_bwd(const T* dy, const T* x, const T* scale, const flo
         hipLaunchKernelGGL((rmsnorm_bwd_kernel<T, 8>), dim3(nb), dim3(256), lds_bytes, st, dy, x, scale, rstd, dres, dx, workspace, rows, dim);
     else { ssi_set_error("rmsnorm_bwd: dim %d too large", dim); return SSI_ERR_UNSUPPORTED; }
     SSI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_accum_kernel<T>, dim3((unsigned)ssi_cdiv(dim, 64)), dim3(256), 0, st, (const float*)workspace, dscale, nb, dim);
+    hipLaunchKernelGGL(colsum_accum_kernel<T>, dim3((unsigned)ssi_cdiv(dim, 64)), dim3(1024), 0, st, (const float*)workspace, dscale, nb, dim);
     return SSI_OK;
 }
 

@@ -143,8 +143,9 @@ bool ssi_gemm_swiglu_supported(int64_t M, int64_t inter, int64_t K, const void* 
                                int64_t ld0, int64_t ld1, int64_t ld2, int64_t ld3);
 int ssi_gemm_swiglu_fwd_mfma(int64_t M, int64_t inter, int64_t K, const void* X, int64_t ldx, const void* W13, int64_t ldw,
                              void* GU, int64_t ldgu, void* ACT, int64_t ldact, void* stream);
-int ssi_gemm_swiglu_bwd_mfma(int64_t M, int64_t inter, int64_t K, const void* DY, int64_t lddy, const void* W2T, int64_t ldw,
+int ssi_gemm_swiglu_bwd_mfma(int layout, int64_t M, int64_t inter, int64_t K, const void* DY, int64_t lddy, const void* W2, int64_t ldw,
                              const void* GU, int64_t ldgu, void* DGU, int64_t lddgu, void* stream);
+bool ssi_gemm_swiglu_bwd_nn_supported(int64_t K, int64_t lddy, int64_t ldw);
 
 extern "C" int ssi_gemm_swiglu_fwd(int64_t M, int64_t inter, int64_t K, const void* X, int64_t ldx, const void* W13, int64_t ldw,
                                    void* GU, int64_t ldgu, void* ACT, int64_t ldact, int dtype, void* stream) {
@@ -163,9 +164,9 @@ extern "C" int ssi_gemm_swiglu_bwd(int layout, int64_t M, int64_t inter, int64_t
                                    void* stream) {
     SSI_CHECK_ARG(DY && W2 && GU && DGU && M >= 0 && inter > 0 && K > 0 && ldgu >= 2 * inter && lddgu >= 2 * inter);
     SSI_CHECK_ARG(layout == SSI_GEMM_NT || layout == SSI_GEMM_NN);
-    if (layout == SSI_GEMM_NT && dtype == SSI_BF16 && g_impl != SSI_IMPL_GENERIC &&
-        ssi_gemm_swiglu_supported(M, inter, K, DY, W2, GU, DGU, lddy, ldw, ldgu, lddgu))
-        return ssi_gemm_swiglu_bwd_mfma(M, inter, K, DY, lddy, W2, ldw, GU, ldgu, DGU, lddgu, stream);
+    if (dtype == SSI_BF16 && g_impl != SSI_IMPL_GENERIC && ssi_gemm_swiglu_supported(M, inter, K, DY, W2, GU, DGU, lddy, ldw, ldgu, lddgu) &&
+        (layout == SSI_GEMM_NT || ssi_gemm_swiglu_bwd_nn_supported(K, lddy, ldw)))
+        return ssi_gemm_swiglu_bwd_mfma(layout, M, inter, K, DY, lddy, W2, ldw, GU, ldgu, DGU, lddgu, stream);
     SSI_CHECK_ARG(dact_ws != nullptr && ldgu == 2 * inter && lddgu == 2 * inter);
     if (int rc = ssi_gemm(layout, M, inter, K, DY, lddy, W2, ldw, dact_ws, inter, nullptr, 1.f, nullptr, 0, dtype, stream)) return rc;
     return ssi_swiglu_bwd(dact_ws, GU, DGU, M, inter, dtype, stream);

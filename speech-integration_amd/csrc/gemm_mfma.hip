@@ -472,10 +472,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, BUF_RSRC_DW3);
 }
 
-// COL: false = both operands k-contiguous (NT), true = both k-strided (TN, the weight-gradient form: operand tiles are
-//      [64 k][256 columns] images read back with ds_read_b64_tr_b16, as in the 8-wave kernel)
+// A_COL / B_COL: false = the operand is k-contiguous in memory, true = k-strided (its tile is a [64 k][256 columns] image read
+//      back with ds_read_b64_tr_b16, as in the 8-wave kernel).  NT = (false, false), NN = (false, true: data gradients against
+//      the untransposed weights), TN = (true, true: weight gradients)
 // PREV: 0 = C is overwritten, 1 = C += result (accumulate), 2 = C = R + result (residual)
-template <bool COL, int EPI, int PREV>
+template <bool A_COL, bool B_COL, int EPI, int PREV>
 __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, int tiles_n, int64_t K, const bf16_t* __restrict__ A,
                                                                   int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                                   bf16_t* __restrict__ C, int64_t ldc, const bf16_t* __restrict__ R,
@@ -500,14 +501,9 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     auto set_load_tile = [&](int v) {
         int tm, tn;
         tile_coords(v, tiles_m, tiles_n, tm, tn);
-        if (COL) {
-            baseA = A + (int64_t)tm * BM;
-            baseB = B + (int64_t)tn * BN;
-        } else {
-            baseA = A + (int64_t)tm * BM * lda;
-            // SwiGLU forward: the 256 tile columns are [gate 0..63 | up 0..63 | gate 64..127 | up 64..127] of 128 W13 column pairs
-            baseB = B + (int64_t)tn * (EPI == EPI_SWIGLU_FWD ? BN / 2 : BN) * ldb;
-        }
+        baseA = A_COL ? A + (int64_t)tm * BM : A + (int64_t)tm * BM * lda;
+        // SwiGLU forward: the 256 tile columns are [gate 0..63 | up 0..63 | gate 64..127 | up 64..127] of 128 W13 column pairs
+        baseB = B_COL ? B + (int64_t)tn * BN : B + (int64_t)tn * (EPI == EPI_SWIGLU_FWD ? BN / 2 : BN) * ldb;
     };
     auto advance = [&]() {
         if (++lkt == nk) {
@@ -520,33 +516,35 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     // k-rows p*8 + (tid >> 5), chunk (tid & 31) swizzled on the SOURCE side (LDS image lane-linear); the swizzle term
     // col_swz(k-row) only depends on p through its parity.  One VGPR byte offset per operand (two for COL); the (piece,
     // K-tile) part rides in the scalar offset of the buffer load.
-    auto lane_off = [&](int64_t ld, int odd) {
-        if (COL) return (int)(((tid >> 5) * ld + (((tid & 31) ^ col_swz(odd * 8 + (tid >> 5))) * 8)) * 2);
+    auto lane_off = [&](bool col, int64_t ld, int odd) {
+        if (col) return (int)(((tid >> 5) * ld + (((tid & 31) ^ col_swz(odd * 8 + (tid >> 5))) * 8)) * 2);
         return (int)(((tid >> 3) * ld + (tid & 7) * 8) * 2);
     };
-    const int offA0 = lane_off(lda, 0), offA1 = COL ? lane_off(lda, 1) : offA0;
-    const int offB0 = lane_off(ldb, 0), offB1 = COL ? lane_off(ldb, 1) : offB0;
-    const int64_t kstepA = COL ? BK * lda : BK, kstepB = COL ? BK * ldb : BK;  // elements per K-step: added to the (64-bit) buffer base
-    auto pieceA = [&](int p) { return COL ? (int)(p * 8 * lda * 2) : (int)(p * 32 * lda * 2); };
+    const int offA0 = lane_off(A_COL, lda, 0), offA1 = A_COL ? lane_off(true, lda, 1) : offA0;
+    const int offB0 = lane_off(B_COL, ldb, 0), offB1 = B_COL ? lane_off(true, ldb, 1) : offB0;
+    const int64_t kstepA = A_COL ? BK * lda : BK, kstepB = B_COL ? BK * ldb : BK;  // elements per K-step: added to the (64-bit) buffer base
+    auto pieceA = [&](int p) { return A_COL ? (int)(p * 8 * lda * 2) : (int)(p * 32 * lda * 2); };
     auto pieceB = [&](int p) {
-        if (COL) return (int)(p * 8 * ldb * 2);
+        if (B_COL) return (int)(p * 8 * ldb * 2);
         if (EPI == EPI_SWIGLU_FWD) {
             const int blk64 = p >> 1;  // 64-row block of the tile: 0 gate lo, 1 up lo, 2 gate hi, 3 up hi
             return (int)((((blk64 & 1) ? ea.inter : 0) + (blk64 >> 1) * 64 + (p & 1) * 32) * ldb * 2);
         }
         return (int)(p * 32 * ldb * 2);
     };
-    const int st_ofs = COL ? tid * 16 : (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) * 16);
+    const int st_row = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) * 16);
+    const int st_ofsA = A_COL ? tid * 16 : st_row, st_ofsB = B_COL ? tid * 16 : st_row;
     auto gloadA = [&](u32x4& dst, int p) { dst = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(baseA + lkt * kstepA), (p & 1) ? offA1 : offA0, pieceA(p), 0); };
     auto gloadB = [&](u32x4& dst, int p) { dst = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(baseB + lkt * kstepB), (p & 1) ? offB1 : offB0, pieceB(p), 0); };
-    auto lwrite1 = [&](char* tile, int p, const u32x4& v) { *reinterpret_cast<u32x4*>(tile + st_ofs + p * 4096) = v; };
+    auto lwriteA = [&](char* tile, int p, const u32x4& v) { *reinterpret_cast<u32x4*>(tile + st_ofsA + p * 4096) = v; };
+    auto lwriteB = [&](char* tile, int p, const u32x4& v) { *reinterpret_cast<u32x4*>(tile + st_ofsB + p * 4096) = v; };
 
     bf16x8 S0[4], S1[4], S2[4], S3[4];  // fragment slots; roles rotate through one K-step (see body)
     // COL fragments: the address of 16-column group t (0..7) of a wave's operand is (group-0 address) XOR (t << 5) — the
     // swizzle only touches the three chunk bits that t occupies — so one per-lane base per operand serves all 8 groups; the
     // XOR is redone per read (kept from being hoisted into 16 live registers by the asm in body).
     int trA = 0, trB = 0;
-    if (COL) {
+    if (A_COL || B_COL) {
         const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, k0l = 8 * (lane >> 4) + q;
         const int common = k0l * 512 + (pp >> 1) * 16 + 8 * (pp & 1) + (col_swz(k0l) << 4);
         trA = common + wm * 256;
@@ -562,11 +560,11 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
         return __builtin_bit_cast(bf16x8, r);
     };
     auto rdA1 = [&](bf16x8& dst, const char* la, int half, int kh, int i) {
-        if (COL) dst = rd_tr(la, trA, half * 4 + i, kh);
+        if (A_COL) dst = rd_tr(la, trA, half * 4 + i, kh);
         else dst = read_frag<false>(la, wm * NT4_WM + (half * 4 + i) * 16, kh, lane);
     };
     auto rdB1 = [&](bf16x8& dst, const char* lb, int half, int kh, int j) {
-        if (COL) dst = rd_tr(lb, trB, half * 4 + j, kh);
+        if (B_COL) dst = rd_tr(lb, trB, half * 4 + j, kh);
         else dst = read_frag<false>(lb, wn * NT4_WN + (half * 4 + j) * 16, kh, lane);
     };
     // one block = 16 MFMAs (4 m-tiles of slot a x 4 n-tiles of slot b); extra(q) is issued right after MFMA q and pinned there.
@@ -587,7 +585,8 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     // entry: S0 = A rows-lo k-lo, S1 = B cols-lo k-lo of this K-step (LDS buffer cur = K-step parity); (xa, xb) hold the next K-step
     auto body = [&](auto cur_c, u32x4 (&xa)[8], u32x4 (&xb)[8], auto first) {
         constexpr int cur = decltype(cur_c)::value;
-        if (COL) asm volatile("" : "+v"(trA), "+v"(trB));
+        if (A_COL) asm volatile("" : "+v"(trA));
+        if (B_COL) asm volatile("" : "+v"(trB));
         const char* la = tileA(cur);
         const char* lb = tileB(cur);
         char* na = tileA(cur ^ 1);
@@ -599,7 +598,7 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
             const int pc = b * 3 + ((q - 4) >> 2);
             if (pc >= 16) return;
             if ((q & 3) == 0) {
-                if (pc < 8) lwrite1(na, pc, xa[pc]); else lwrite1(nb, pc - 8, xb[pc - 8]);
+                if (pc < 8) lwriteA(na, pc, xa[pc]); else lwriteB(nb, pc - 8, xb[pc - 8]);
             } else {
                 if (pc < 8) gloadA(xa[pc], pc); else gloadB(xb[pc - 8], pc - 8);
             }
@@ -626,9 +625,9 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     set_load_tile(lv);
     fetch_step(ra0, rb0);
 #pragma unroll
-    for (int p = 0; p < 8; ++p) lwrite1(tileA(0), p, ra0[p]);
+    for (int p = 0; p < 8; ++p) lwriteA(tileA(0), p, ra0[p]);
 #pragma unroll
-    for (int p = 0; p < 8; ++p) lwrite1(tileB(0), p, rb0[p]);
+    for (int p = 0; p < 8; ++p) lwriteB(tileB(0), p, rb0[p]);
     fetch_step(ra1, rb1);
     fetch_step(ra0, rb0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -810,10 +809,10 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     }
 }
 
-template <bool COL, int EPI, int PREV>
+template <bool A_COL, bool B_COL, int EPI, int PREV>
 int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                const void* R, float alpha, const float* alpha_dev, hipStream_t st, EpiArgs ea = EpiArgs{nullptr, 0, nullptr, 0, 0}) {
-    auto kern = gemm_nt4_kernel<COL, EPI, PREV>;
+    auto kern = gemm_nt4_kernel<A_COL, B_COL, EPI, PREV>;
     static bool attr_set = false;  // per instantiation
     static int num_cu = 256;
     if (!attr_set) {
@@ -860,17 +859,23 @@ int ssi_gemm_mfma_bf16(int layout, int64_t M, int64_t N, int64_t K, const void* 
     switch (layout) {
         case SSI_GEMM_NT:
             if (nt4_ok(K) && nt4_ld_ok(lda, ldb) && !(accumulate && R)) {
-                if (accumulate) return launch_nt4<false, EPI_PLAIN, 1>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
-                if (R) return launch_nt4<false, EPI_PLAIN, 2>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
-                return launch_nt4<false, EPI_PLAIN, 0>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (accumulate) return launch_nt4<false, false, EPI_PLAIN, 1>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (R) return launch_nt4<false, false, EPI_PLAIN, 2>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                return launch_nt4<false, false, EPI_PLAIN, 0>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
             }
             GO(false, false);
-        case SSI_GEMM_NN: GO(false, true);
+        case SSI_GEMM_NN:
+            if (nt4_ok(K) && nt4_ld_ok(lda, ldb) && !(accumulate && R)) {
+                if (accumulate) return launch_nt4<false, true, EPI_PLAIN, 1>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (R) return launch_nt4<false, true, EPI_PLAIN, 2>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                return launch_nt4<false, true, EPI_PLAIN, 0>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+            }
+            GO(false, true);
         case SSI_GEMM_TN:
             if (nt4_ok(K) && nt4_ld_ok(lda, ldb) && !(accumulate && R)) {
-                if (accumulate) return launch_nt4<true, EPI_PLAIN, 1>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
-                if (R) return launch_nt4<true, EPI_PLAIN, 2>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
-                return launch_nt4<true, EPI_PLAIN, 0>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (accumulate) return launch_nt4<true, true, EPI_PLAIN, 1>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (R) return launch_nt4<true, true, EPI_PLAIN, 2>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                return launch_nt4<true, true, EPI_PLAIN, 0>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
             }
             GO(true, true);
     }
@@ -906,20 +911,28 @@ int ssi_gemm_swiglu_fwd_mfma(int64_t M, int64_t inter, int64_t K, const void* X,
                              void* GU, int64_t ldgu, void* ACT, int64_t ldact, void* stream) {
     EpiArgs ea{(bf16_t*)ACT, ldact, nullptr, 0, inter};
     if (nt4_ok(K))
-        return launch_nt4<false, EPI_SWIGLU_FWD, 0>((int)(M / BM), (int)(2 * inter / BN), K, X, ldx, W13, ldw, GU, ldgu, nullptr, 1.f, nullptr,
+        return launch_nt4<false, false, EPI_SWIGLU_FWD, 0>((int)(M / BM), (int)(2 * inter / BN), K, X, ldx, W13, ldw, GU, ldgu, nullptr, 1.f, nullptr,
                                              (hipStream_t)stream, ea);
     // output tiles: 256 rows x (128 gate + 128 up) columns -> tiles_n = 2I / 256
     return launch<false, false, false, EPI_SWIGLU_FWD>((int)(M / BM), (int)(2 * inter / BN), K, X, ldx, W13, ldw, GU, ldgu, nullptr, 1.f,
                                                        nullptr, 0, (hipStream_t)stream, 1, nullptr, ea);
 }
 
-int ssi_gemm_swiglu_bwd_mfma(int64_t M, int64_t inter, int64_t K, const void* DY, int64_t lddy, const void* W2T, int64_t ldw,
+int ssi_gemm_swiglu_bwd_mfma(int layout, int64_t M, int64_t inter, int64_t K, const void* DY, int64_t lddy, const void* W2, int64_t ldw,
                              const void* GU, int64_t ldgu, void* DGU, int64_t lddgu, void* stream) {
     EpiArgs ea{(bf16_t*)DGU, lddgu, (const bf16_t*)GU, ldgu, inter};
-    if (nt4_ok(K))
-        return launch_nt4<false, EPI_SWIGLU_BWD, 0>((int)(M / BM), (int)(inter / BN), K, DY, lddy, W2T, ldw, DGU, lddgu, nullptr, 1.f, nullptr,
-                                             (hipStream_t)stream, ea);
-    // d act [M, I] = DY [M, K] * W2T[I, K]^T; the tile never reaches memory
-    return launch<false, false, false, EPI_SWIGLU_BWD>((int)(M / BM), (int)(inter / BN), K, DY, lddy, W2T, ldw, DGU, lddgu, nullptr, 1.f,
-                                                       nullptr, 0, (hipStream_t)stream, 1, nullptr, ea);
+    // d act [M, I] = DY [M, K] * W2 (NN: W2 [K, I]) or * W2T^T (NT: transposed copy [I, K]); the tile never reaches memory
+    const int tm = (int)(M / BM), tn = (int)(inter / BN);
+    if (layout == SSI_GEMM_NN) {
+        if (nt4_ok(K) && nt4_ld_ok(lddy, ldw))
+            return launch_nt4<false, true, EPI_SWIGLU_BWD, 0>(tm, tn, K, DY, lddy, W2, ldw, DGU, lddgu, nullptr, 1.f, nullptr, (hipStream_t)stream, ea);
+        return SSI_ERR_UNSUPPORTED;
+    }
+    if (nt4_ok(K) && nt4_ld_ok(lddy, ldw))
+        return launch_nt4<false, false, EPI_SWIGLU_BWD, 0>(tm, tn, K, DY, lddy, W2, ldw, DGU, lddgu, nullptr, 1.f, nullptr, (hipStream_t)stream, ea);
+    return launch<false, false, false, EPI_SWIGLU_BWD>(tm, tn, K, DY, lddy, W2, ldw, DGU, lddgu, nullptr, 1.f, nullptr, 0, (hipStream_t)stream, 1,
+                                                       nullptr, ea);
 }
+
+// NN form of the fused SwiGLU backward exists only on the persistent kernel
+bool ssi_gemm_swiglu_bwd_nn_supported(int64_t K, int64_t lddy, int64_t ldw) { return nt4_ok(K) && nt4_ld_ok(lddy, ldw); }

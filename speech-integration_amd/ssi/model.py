@@ -21,6 +21,8 @@ MI355X-first design (not a module-per-op port):
 
 from __future__ import annotations
 
+import os
+
 import logging
 import math
 from typing import Any, Optional
@@ -247,6 +249,10 @@ class HipLlamaDecoder(nn.Module):
                     p.copy_(src.to(device=self.device, dtype=self.dtype))
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
+    # Data gradients dX = dY W run on the untransposed weights (NN form of the persistent GEMM, as fast as the k-contiguous
+    # form); SSI_DGRAD_NT=1 restores the older scheme of [in, out] weight copies refreshed after every optimizer step.
+    transposed_weight_copies = os.environ.get("SSI_DGRAD_NT", "0") == "1"
+
     def _view_t(self, name: str) -> Tensor:
         o, shape = self._slices[name]
         return self._flat_t[o:o + shape[0] * shape[1]].view(shape[1], shape[0])
@@ -254,7 +260,7 @@ class HipLlamaDecoder(nn.Module):
     def _ensure_transposed(self) -> bool:
         """Refresh the transposed weight copies if any weight changed since the last refresh.  Returns whether the
         transposed copies are in use (bf16 MFMA shapes only)."""
-        if not self._mfma_shapes():
+        if not self.transposed_weight_copies or not self._mfma_shapes():
             return False
         key = (self._flat._version, self._hip_epoch)
         if self._flat_t is None:

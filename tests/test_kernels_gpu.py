@@ -289,7 +289,7 @@ def test_gemm_mfma_bf16(ops, impl_name, layout, M, N, K):
         ops.set_impl(prev)
 
 
-@pytest.mark.parametrize("layout", [0, 2])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("mode", ["plain", "accumulate", "residual"])
 def test_gemm_persistent_kernel_walks_many_tiles(ops, layout, mode):
     """4-wave persistent kernel (NT and TN forms): 512 output tiles on 256 CUs, so every workgroup runs its tile loop twice
@@ -311,7 +311,7 @@ def test_gemm_persistent_kernel_walks_many_tiles(ops, layout, mode):
             ops.set_impl(prev)
     assert torch.equal(outs[0], outs[1])
     if mode == "plain":
-        ref = (a.float() @ b.float().t()) if layout == 0 else (a.float().t() @ b.float())
+        ref = (a.float() @ b.float().t()) if layout == 0 else ((a.float() @ b.float()) if layout == 1 else (a.float().t() @ b.float()))
         exact = ref.abs() <= 256
         assert torch.equal(outs[0].float()[exact], ref[exact])
     # random data, longer K: still bit-identical (same accumulation order in both kernels)
@@ -502,6 +502,9 @@ def test_fused_swiglu_gemms_equal_the_unfused_kernels(ops):
     dgu = torch.full_like(gu_ref, float("nan"))
     ops.gemm_swiglu_bwd(ops.GEMM_NT, dy, w2t, gu_ref, dgu, None)
     assert torch.equal(dgu, dgu_ref)
+    dgu_nn = torch.full_like(gu_ref, float("nan"))   # same product against the untransposed weight [K, I] (NN form), also fused
+    ops.gemm_swiglu_bwd(ops.GEMM_NN, dy, w2t.t().contiguous(), gu_ref, dgu_nn, None)
+    assert torch.equal(dgu_nn, dgu_ref)
     # against fp32 math on the CPU
     xr, wr = x.float().cpu(), w13.float().cpu()
     g = (xr @ wr.T).bfloat16().float()

@@ -231,10 +231,11 @@ def itertools_islice(loader, n):
     return list(itertools.islice(iter(loader), n))
 
 
-def test_bf16_mfma_shaped_model_matches_oracle_and_refreshes_transposed_weights():
-    """A model whose dims satisfy the MFMA tile rules (so the MFMA GEMMs, split-K weight gradients, the transposed-weight
-    data-gradient path and MFMA attention all run), against the fp32 CPU oracle; then an optimizer step must refresh the
-    transposed weight copies."""
+@pytest.mark.parametrize("transposed_copies", [False, True])
+def test_bf16_mfma_shaped_model_matches_oracle(transposed_copies):
+    """A model whose dims satisfy the MFMA tile rules (so the MFMA GEMMs, split-K weight gradients and MFMA attention all
+    run), against the fp32 CPU oracle, with the data gradients either on the untransposed weights (NN form, the default)
+    or on [in, out] weight copies (NT form, SSI_DGRAD_NT=1), which an optimizer step must refresh."""
     from oracle import hf_crosscheck as hx
     from oracle.llama_oracle import OracleCEWithChunkedOutputLoss
     from oracle.llama_oracle import compute_loss as oracle_loss
@@ -245,6 +246,7 @@ def test_bf16_mfma_shaped_model_matches_oracle_and_refreshes_transposed_weights(
     sd = hx.seeded_state_dict(params, 21)
     batch = hx.seeded_batch(700, 2, 128, 21)
     model = HipLlamaDecoder(**params, dtype=torch.bfloat16, device=DEV)
+    model.transposed_weight_copies = transposed_copies
     model.load_state_dict(sd)
     assert model._mfma_shapes()
     ref_model = hx.oracle_model(params, sd)
@@ -254,9 +256,10 @@ def test_bf16_mfma_shaped_model_matches_oracle_and_refreshes_transposed_weights(
     loss = compute_loss(dbatch, model, CEWithChunkedOutputLoss())
     loss.backward()
     assert abs(loss.item() - ref.item()) <= 1e-2 * abs(ref.item())
-    assert model._flat_t is not None
-    for name in ("emb", "L0.wqkv", "L1.w2"):
-        assert torch.equal(model._view_t(name), model._view(name).t())
+    assert (model._flat_t is not None) == transposed_copies
+    if transposed_copies:
+        for name in ("emb", "L0.wqkv", "L1.w2"):
+            assert torch.equal(model._view_t(name), model._view(name).t())
     for (k, p), (_, p2) in zip(model.named_parameters(), ref_model.named_parameters()):
         g, g2 = p.grad.float().cpu(), p2.grad
         rel = float((g - g2).norm() / g2.norm())
@@ -268,9 +271,10 @@ def test_bf16_mfma_shaped_model_matches_oracle_and_refreshes_transposed_weights(
     opt.zero_grad(set_to_none=True)
     l2 = compute_loss(dbatch, model, CEWithChunkedOutputLoss())
     l2.backward()
-    assert model._wt_key != key_before
-    for name in ("emb", "L0.wqkv", "L1.w2"):
-        assert torch.equal(model._view_t(name), model._view(name).t())
+    if transposed_copies:
+        assert model._wt_key != key_before
+        for name in ("emb", "L0.wqkv", "L1.w2"):
+            assert torch.equal(model._view_t(name), model._view(name).t())
     assert l2.item() < loss.item()  # the step reduced the loss on the same batch
 
 
