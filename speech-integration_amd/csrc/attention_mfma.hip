@@ -17,7 +17,18 @@
 #include <type_traits>
 #include "common.cuh"
 
+#ifndef DKV_RING
+#define DKV_RING 6
+#endif
+#ifndef DKV_WAVES
+#define DKV_WAVES 2
+#endif
 namespace {
+
+// Workgroup barrier for the LDS-DMA rings.  __syncthreads() would do, except that hipcc puts `s_waitcnt vmcnt(0)` in front of
+// its s_barrier: that waits for the prefetches of the NEXT steps as well and exposes their whole memory latency every step.
+// Here the counted vmcnt wait for this step's pieces is written out by the caller; only LDS traffic is drained.
+__device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int HD = 64;
 constexpr float LOG2E = 1.4426950408889634f;
@@ -150,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         const char* vt = kt + 8192;
         if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // own pieces of tile t landed (tile t+1 may fly)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // everybody's pieces landed; the slot of tile t-1 is free again
+        ring_barrier();  // everybody's pieces landed; the slot of tile t-1 is free again
         if (t + 2 < nt) dma_kv_tile<SWZ_ROW, SWZ_TR>(kbase, vbase, ld, t + 2, smem + ((BUF + 2) % 3) * 16384, wave, lane);
         const int k0 = t * 64;
         if (k0 <= q0 + 31) {  // wave-uniform: this tile intersects the causal range of the wave's rows
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         const char* vt = kt + 8192;
         if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // own pieces of tile t landed (tile t+1 may fly)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // everybody's pieces landed; the slot of tile t-1 is free again
+        ring_barrier();  // everybody's pieces landed; the slot of tile t-1 is free again
         if (t + 2 < nt) dma_kv_tile<SWZ_ROW, SWZ_ROW>(kbase, vbase, ld, t + 2, smem + ((BUF + 2) % 3) * 16384, wave, lane);
         const int k0 = t * 64;
         if (k0 <= q0 + 31) {
@@ -358,13 +369,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // buffered, one step ahead), so Q and dO cross the L2 -> CU path once per 128 keys instead of once per 32, and the sum
 // over the query heads of the group happens in registers: no cross-wave reduction, no partial buffers, one writer per
 // output element.
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+__global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S,
                                                            int H, int KV) {
-    // ring of 3 step buffers: [Q tile 4 KiB | dO tile 4 KiB | lse 128 B | delta 128 B]; requests run two steps ahead
+    // ring of RING step buffers: [Q tile 4 KiB | dO tile 4 KiB | lse 128 B | delta 128 B]; requests run RING-1 steps ahead
     constexpr int SB = 8192 + 256;
-    __shared__ __attribute__((aligned(16))) char smem[3 * SB];
+    constexpr int RING = DKV_RING;
+    __shared__ __attribute__((aligned(16))) char smem[RING * SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep = H / KV;
     const int ngrp = S / 128;
@@ -404,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         const int head = kvh * rep + step / per_head, q0 = (qb_first + step % per_head) * 32;
         const int row = wave * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ swz<SWZ_ROW>(row);
-        char* buf = smem + (step % 3) * SB;
+        char* buf = smem + (step % RING) * SB;
         __builtin_amdgcn_global_load_lds(
             (__attribute__((address_space(1))) const void*)(qkv + (row0 + q0 + row) * ld + (int64_t)head * HD + chunk * 8),
             (__attribute__((address_space(3))) void*)(buf + wave * 1024), 16, 0, 0);
@@ -424,11 +436,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         const char* qt = smem + BUF * SB;
         const char* dt = qt + 4096;
         const float* rcs = reinterpret_cast<const float*>(qt + 8192);
-        // own requests of this step have landed (the next step's 3 may stay in flight) ...
-        if (step + 1 < n_steps) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // ... and everybody else's; the buffer of step-1 is free again
-        if (step + 2 < n_steps) issue(step + 2);
+        if constexpr (BUF % 2 == 0) {
+            // one barrier per TWO steps: own requests of this step and the next have landed (later ones may stay in flight) ...
+            if (step + RING - 3 < n_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (RING - 4)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail: fewer requests are in flight than the constant assumes
+            ring_barrier();  // ... and everybody else's; the buffers of steps -1 and -2 are free again
+            if (step + RING - 2 < n_steps) issue(step + RING - 2);
+            if (step + RING - 1 < n_steps) issue(step + RING - 1);
+        }
         if (q0 + 31 < key0) return;  // wave-uniform: every key of this wave is in the future of every query of the tile
         f32x16 sacc, pacc;  // rows = queries q0 + rowmap(r, h): row constants come in runs of 4
 #pragma unroll
@@ -469,12 +484,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
             }
         }
     };
-    issue(0);
-    if (n_steps > 1) issue(1);
-    for (int step = 0; step < n_steps; step += 3) {
+#pragma unroll
+    for (int i = 0; i < RING - 2; ++i)
+        if (i < n_steps) issue(i);
+    for (int step = 0; step < n_steps; step += RING) {
         do_step(step, std::integral_constant<int, 0>{});
         if (step + 1 < n_steps) do_step(step + 1, std::integral_constant<int, 1>{});
         if (step + 2 < n_steps) do_step(step + 2, std::integral_constant<int, 2>{});
+        if constexpr (RING > 3) {
+            if (step + 3 < n_steps) do_step(step + 3, std::integral_constant<int, 3 % RING>{});
+            if (step + 4 < n_steps) do_step(step + 4, std::integral_constant<int, 4 % RING>{});
+            if (step + 5 < n_steps) do_step(step + 5, std::integral_constant<int, 5 % RING>{});
+        }
     }
     // lane = key, registers = d (runs of 4): 8-byte stores into the k and v column blocks of dqkv
     bf16_t* krow_out = dqkv + (row0 + kg) * ld + (int64_t)H * HD + (int64_t)kvh * HD;
