@@ -464,6 +464,10 @@ int launch(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, cons
 //     (16-B stores, 64 B per row per instruction); no LDS, so the operand stream keeps running underneath it.
 // Requires K % 128 == 0 and not both `accumulate` and R; other NT calls use the 8-wave kernel above.
 // =====================================================================================================================
+// cache-policy bits of the epilogue stores (2 = nt, 16 = sc1): measured neutral on the step's shapes, left at the default
+#ifndef NT4_ST_AUX
+#define NT4_ST_AUX 0
+#endif
 constexpr int NT4_THREADS = 256;
 constexpr int NT4_WM = 128, NT4_WN = 128;
 constexpr unsigned BUF_RSRC_DW3 = 0x00020000u;  // raw buffer, 32-bit data format (gfx9 family)
@@ -712,8 +716,8 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
                     u32x4 lo, hi;
                     duo(i, jd * 4, scale_c, lo, hi);
                     if (PREV) { add_prev(lo, pv[i & 1][jd * 2]); add_prev(hi, pv[i & 1][jd * 2 + 1]); }
-                    __builtin_amdgcn_raw_buffer_store_b128(lo, rsC, voff, soff(i, 0, jd), 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(hi, rsC, voff, soff(i, 1, jd), 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(lo, rsC, voff, soff(i, 0, jd), NT4_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(hi, rsC, voff, soff(i, 1, jd), NT4_ST_AUX);
                     __builtin_amdgcn_sched_barrier(0);  // one duo at a time: bounded register pressure
                 }
             }
@@ -745,9 +749,9 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
                     const u32x4& gq = h ? ghi : glo;
                     const u32x4& uq = h ? uhi : ulo;
                     const int so = (int)(((i * 16 + h * 8) * ldc) * 2), so2 = (int)(((i * 16 + h * 8) * ea.ld_out2) * 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(gq, rsGU, voff, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(uq, rsGU, voff, so + up_off, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(act_of(gq, uq), rsACT, voff2, so2, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(gq, rsGU, voff, so, NT4_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(uq, rsGU, voff, so + up_off, NT4_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(act_of(gq, uq), rsACT, voff2, so2, NT4_ST_AUX);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -793,8 +797,8 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
                     u32x4 og, ou;
                     grads(h ? hi : lo, pg[u & 1][h], pu[u & 1][h], og, ou);
                     const int so2 = (int)(((i * 16 + h * 8) * ea.ld_out2 + jd * 64) * 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(og, rsDGU, voff2, so2, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(ou, rsDGU, voff2, so2 + up_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(og, rsDGU, voff2, so2, NT4_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(ou, rsDGU, voff2, so2 + up_off, NT4_ST_AUX);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
