@@ -1,13 +1,13 @@
-"""Minimal checkpoint I/O for the hot path (torchtune-key safetensors + schema-v1 ``training_state.pt``).
+"""Checkpoint I/O either side of the hot path.
 
-The reference's ``FullModelHFCheckpointer`` (``/root/reference/ssi/checkpoint.py:209-468``: HF<->torchtune key conversion,
-shard discovery, config.json validation) is disk I/O outside the step path and is NOT rebuilt this round (SURVEY.md §8f
-rank 3).  What the trainer needs from a checkpointer is kept, with the same method names:
-``load_checkpoint() -> {"model": state_dict | None, ...training-state keys}``,
-``save_model_checkpoint(state_dict, step)``, ``save_training_state(...)`` (schema v1 keys, ``constants.py:78-89``),
-``training_state_checkpoint``.  Weights are read/written as ONE safetensors file whose keys are the torchtune names the
-model exposes (``tok_embeddings.weight``, ``layers.{i}.attn.q_proj.weight``, ...); with no weights on disk the model is
-random-initialised (seeded) — there are no Llama weights on the build/GPU image and no network."""
+``FullModelHFCheckpointer`` (second half of this file) reads and writes HF-format Llama-3.2 model directories exactly as the
+reference's class of the same name does (``/root/reference/ssi/checkpoint.py:209-468``): sharded safetensors, config.json
+validation, HF<->torchtune key map with the q/k row permutation, ``step_N/`` output directories, schema-v1
+``training_state.pt`` (``constants.py:78-89``).  ``TuneCheckpointer`` is the single-file variant used when ``checkpoint_dir`` is
+not an HF model directory: ONE safetensors file whose keys are the torchtune names the model exposes; with no weights on disk
+the model is random-initialised (seeded) — there are no Llama weights on the build/GPU image and no network.  Both expose
+``load_checkpoint() -> {"model": state_dict | None, ...training-state keys}``, ``save_model_checkpoint(state_dict, step)``,
+``save_training_state(...)``, ``training_state_checkpoint``; ``make_checkpointer`` picks one."""
 
 from __future__ import annotations
 
@@ -102,3 +102,225 @@ class TuneCheckpointer:
             TRAINING_HPARAMS_KEY: training_hparams, CONSUMED_SAMPLES_KEY: consumed_samples,
             CUMULATIVE_METRICS_KEY: cumulative_metrics}, path)
         return path
+
+
+# =====================================================================================================================
+# HF-format checkpoints: the on-disk format either side of the hot path.
+# Mirrors the reference's ``FullModelHFCheckpointer`` (``/root/reference/ssi/checkpoint.py:209-468``) and the torchtune 0.5.0
+# ``convert_weights.hf_to_tune / tune_to_hf`` it calls (``:325-331, :352-358``; key map and q/k row permutation restated from
+# SURVEY.md §8b / Appendix A.3).  Only safetensors are read (nothing in a checkpoint file is executed).
+# =====================================================================================================================
+import gc
+import json
+import re
+import shutil
+from pathlib import Path
+
+SHARD_FNAME = "model-{cpt_idx}-of-{num_shards}"
+SAFETENSOR_INDEX_FNAME = "model.safetensors.index.json"
+LLAMA_3_2_CONFIG_RELPATH = Path("config.json")
+SUFFIXES_TO_NOT_COPY = (".safetensors", ".bin", ".pt", ".pth", ".index.json")
+
+_HF_TO_TUNE = {
+    "model.embed_tokens.weight": "tok_embeddings.weight",
+    "model.layers.{}.self_attn.q_proj.weight": "layers.{}.attn.q_proj.weight",
+    "model.layers.{}.self_attn.k_proj.weight": "layers.{}.attn.k_proj.weight",
+    "model.layers.{}.self_attn.v_proj.weight": "layers.{}.attn.v_proj.weight",
+    "model.layers.{}.self_attn.o_proj.weight": "layers.{}.attn.output_proj.weight",
+    "model.layers.{}.mlp.gate_proj.weight": "layers.{}.mlp.w1.weight",
+    "model.layers.{}.mlp.down_proj.weight": "layers.{}.mlp.w2.weight",
+    "model.layers.{}.mlp.up_proj.weight": "layers.{}.mlp.w3.weight",
+    "model.layers.{}.input_layernorm.weight": "layers.{}.sa_norm.scale",
+    "model.layers.{}.post_attention_layernorm.weight": "layers.{}.mlp_norm.scale",
+    "model.norm.weight": "norm.scale",
+    "lm_head.weight": "output.weight",
+}
+_TUNE_TO_HF = {v: k for k, v in _HF_TO_TUNE.items()}
+_LAYER_RE = re.compile(r"(\.layers\.|^layers\.)(\d+)\.")
+
+
+def _map_key(key: str, table: dict[str, str]) -> str:
+    m = _LAYER_RE.search(key)
+    if m is None:
+        if key not in table:
+            raise KeyError(f"unexpected checkpoint key {key!r}")
+        return table[key]
+    generic = key[:m.start(2)] + "{}" + key[m.end(2):]
+    if generic not in table:
+        raise KeyError(f"unexpected checkpoint key {key!r}")
+    return table[generic].format(m.group(2))
+
+
+def _permute_hf_to_tune(w: torch.Tensor, n_heads: int, head_dim: int) -> torch.Tensor:
+    """HF stores q/k projection rows per head as [first halves | second halves] (rotate-half RoPE); torchtune interleaves the
+    pairs (x[2i], x[2i+1]): ``W.view(n, 2, hd/2, dim).transpose(1, 2).reshape(n*hd, dim)``."""
+    dim = w.shape[1]
+    return w.view(n_heads, 2, head_dim // 2, dim).transpose(1, 2).reshape(n_heads * head_dim, dim).contiguous()
+
+
+def _permute_tune_to_hf(w: torch.Tensor, n_heads: int, head_dim: int) -> torch.Tensor:
+    dim = w.shape[1]
+    return w.view(n_heads, head_dim // 2, 2, dim).transpose(1, 2).reshape(n_heads * head_dim, dim).contiguous()
+
+
+def hf_to_tune(state_dict: dict[str, torch.Tensor], num_heads: int, num_kv_heads: int, dim: int,
+               head_dim: int | None = None, tie_word_embeddings: bool = True) -> dict[str, torch.Tensor]:
+    head_dim = head_dim or dim // num_heads
+    out: dict[str, torch.Tensor] = {}
+    for key, value in state_dict.items():
+        if "rotary_emb.inv_freq" in key:
+            continue  # derived buffer, never a parameter
+        if key == "lm_head.weight" and tie_word_embeddings:
+            continue  # tied head: the embedding is the only copy (torchtune's Llama-3.2 builder has no output.weight)
+        new_key = _map_key(key, _HF_TO_TUNE)
+        if new_key.endswith("attn.q_proj.weight"):
+            value = _permute_hf_to_tune(value, num_heads, head_dim)
+        elif new_key.endswith("attn.k_proj.weight"):
+            value = _permute_hf_to_tune(value, num_kv_heads, head_dim)
+        out[new_key] = value
+    return out
+
+
+def tune_to_hf(state_dict: dict[str, torch.Tensor], num_heads: int, num_kv_heads: int, dim: int,
+               head_dim: int | None = None) -> dict[str, torch.Tensor]:
+    head_dim = head_dim or dim // num_heads
+    out: dict[str, torch.Tensor] = {}
+    for key, value in state_dict.items():
+        new_key = _map_key(key, _TUNE_TO_HF)
+        if key.endswith("attn.q_proj.weight"):
+            value = _permute_tune_to_hf(value, num_heads, head_dim)
+        elif key.endswith("attn.k_proj.weight"):
+            value = _permute_tune_to_hf(value, num_kv_heads, head_dim)
+        out[new_key] = value
+    return out
+
+
+def discover_safetensor_files(checkpoint_dir: Path) -> list[str]:
+    """Sorted ``*.safetensors`` shard names of a directory; raises on none, or on both base (``model-*``) and fine-tuned
+    (``ft-model-*``) shards (``/root/reference/ssi/checkpoint.py:53-90``)."""
+    checkpoint_dir = Path(checkpoint_dir)
+    if not checkpoint_dir.exists():
+        raise FileNotFoundError(f"Checkpoint directory does not exist: {checkpoint_dir}")
+    st_files = sorted(f.name for f in checkpoint_dir.glob("*.safetensors"))
+    if not st_files:
+        raise ValueError(f"No safetensors files found in {checkpoint_dir}. Directory contents: {sorted(f.name for f in checkpoint_dir.iterdir())}")
+    if [f for f in st_files if f.startswith("model-")] and [f for f in st_files if f.startswith("ft-model-")]:
+        raise ValueError(f"Ambiguous checkpoint files in {checkpoint_dir}: both base and fine-tuned shards present. "
+                         f"Specify checkpoint_files explicitly to disambiguate.")
+    return st_files
+
+
+def validate_checkpoint_dir(checkpoint_dir: Path, config: dict[str, Any], expectations: Any | None = None) -> None:
+    """Non-destructive checks of config.json against the model the trainer is about to build (layer count, hidden size, vocab
+    size, shard count when the expectations object carries them); ``ValueError`` with the mismatch spelled out."""
+    if expectations is None:
+        return
+    name = getattr(expectations, "model_name", "the model")
+    checks = [("num_hidden_layers", getattr(expectations, "num_layers", None)), ("hidden_size", getattr(expectations, "hidden_size", None)),
+              ("vocab_size", getattr(expectations, "vocab_size", None))]
+    for key, want in checks:
+        if want is not None and key in config and int(config[key]) != int(want):
+            raise ValueError(f"{checkpoint_dir}/config.json has {key}={config[key]}, {name} expects {want}")
+    n_shards = getattr(expectations, "n_shards", None)
+    if n_shards is not None:
+        found = len([f for f in Path(checkpoint_dir).glob("*.safetensors")])
+        if found != int(n_shards):
+            raise ValueError(f"{checkpoint_dir} holds {found} safetensors shard(s), {name} expects {n_shards}")
+
+
+class FullModelHFCheckpointer(TuneCheckpointer):
+    """HF-format Llama-3.2 checkpoints <-> the torchtune-key state dict the model exposes.  Same constructor keywords, methods
+    and on-disk layout as the reference: sharded ``model-0000i-of-0000n.safetensors`` + ``model.safetensors.index.json`` in a
+    self-contained ``step_N/`` directory (config / tokenizer files copied next to the weights), ``training_state.pt`` (schema
+    v1) at the output root."""
+
+    def __init__(self, checkpoint_dir, checkpoint_files: Any = None, *, config_json: Any = None, output_dir,
+                 training_state_checkpoint: Any = None, safe_serialization: bool = True, model_expectations: Any = None, **_: Any) -> None:
+        super().__init__(checkpoint_dir=str(checkpoint_dir), output_dir=str(output_dir),
+                         training_state_checkpoint=str(training_state_checkpoint) if training_state_checkpoint is not None else None,
+                         model_expectations=model_expectations)
+        if not safe_serialization:
+            raise ValueError("only safetensors serialization is supported (pickle-based .bin files are never written or read)")
+        self._ckpt_dir, self._out_dir = Path(checkpoint_dir), Path(output_dir)
+        if self._out_dir.resolve() == self._ckpt_dir.resolve() or self._ckpt_dir.resolve() in self._out_dir.resolve().parents:
+            raise ValueError(f"output_dir {self._out_dir} must not lie inside checkpoint_dir {self._ckpt_dir}")
+        if self.training_state_checkpoint is not None and not Path(self.training_state_checkpoint).is_file():
+            raise FileNotFoundError(f"Recipe checkpoint file {self.training_state_checkpoint} not found.")
+        self._out_dir.mkdir(parents=True, exist_ok=True)
+        config_json = Path(config_json) if config_json is not None else self._ckpt_dir / LLAMA_3_2_CONFIG_RELPATH
+        if not config_json.exists():
+            raise FileNotFoundError(f"No config.json found at {config_json} — expected an HF-format model directory.")
+        self._config = json.loads(config_json.read_text())
+        if checkpoint_files is None:
+            checkpoint_files = discover_safetensor_files(self._ckpt_dir)
+        elif isinstance(checkpoint_files, dict) or (hasattr(checkpoint_files, "keys") and "filename_format" in checkpoint_files):
+            n = int(checkpoint_files["max_filename"])
+            checkpoint_files = [str(checkpoint_files["filename_format"]).format(str(i).zfill(len(str(checkpoint_files["max_filename"]))), checkpoint_files["max_filename"])
+                                for i in range(1, n + 1)]
+        validate_checkpoint_dir(self._ckpt_dir, self._config, model_expectations)
+        self._checkpoint_paths = [self._ckpt_dir / str(f) for f in sorted(str(f) for f in checkpoint_files)]
+        for p in self._checkpoint_paths:
+            if not p.is_file():
+                raise FileNotFoundError(f"checkpoint file {p} not found")
+        self._weight_map: dict[str, str] | None = None
+
+    def _conv_kwargs(self) -> dict[str, Any]:
+        c = self._config
+        return dict(num_heads=c["num_attention_heads"], num_kv_heads=c["num_key_value_heads"], dim=c["hidden_size"], head_dim=c.get("head_dim"))
+
+    def load_checkpoint(self) -> dict[str, Any]:
+        from safetensors.torch import load_file
+        self._weight_map = {}
+        merged: dict[str, torch.Tensor] = {}
+        for idx, path in enumerate(self._checkpoint_paths):
+            shard = load_file(str(path))
+            for key, value in shard.items():
+                if not isinstance(value, torch.Tensor):
+                    raise ValueError(f"Expected all values in the state dict to be torch.Tensor. Found {type(value)} instead.")
+                self._weight_map[key] = f"{idx + 1:04}"
+            merged.update(shard)
+            del shard
+            gc.collect()
+        out: dict[str, Any] = {MODEL_KEY: hf_to_tune(merged, **self._conv_kwargs(), tie_word_embeddings=self._config.get("tie_word_embeddings", True))}
+        if self.training_state_checkpoint is not None:
+            out.update(torch.load(self.training_state_checkpoint, map_location="cpu", weights_only=False))  # own file, own writer
+        return out
+
+    def save_full_model(self, state_dict: dict[str, Any], output_dir: Path) -> None:
+        from safetensors.torch import save_file
+        if self._weight_map is None:
+            raise ValueError("Weight map is not initialized. Please load a checkpoint before saving.")
+        hf_sd = tune_to_hf(state_dict[MODEL_KEY], **self._conv_kwargs())
+        split: dict[str, dict[str, torch.Tensor]] = {}
+        total_size = 0
+        for key, weight in hf_sd.items():
+            shard_id = self._weight_map.get(key, "0001")
+            split.setdefault(shard_id, {})[key] = weight.detach().to("cpu").contiguous()
+            total_size += weight.numel() * weight.element_size()
+        output_dir = Path(output_dir)
+        output_dir.mkdir(parents=True, exist_ok=True)
+        names = {}
+        for shard_id, sd in split.items():
+            names[shard_id] = SHARD_FNAME.format(cpt_idx=f"{shard_id}".zfill(5), num_shards=f"{len(split)}".zfill(5)) + ".safetensors"
+            save_file(sd, str(output_dir / names[shard_id]), metadata={"format": "pt"})
+        weight_map = {k: names[self._weight_map.get(k, "0001")] for k in hf_sd}
+        (output_dir / SAFETENSOR_INDEX_FNAME).write_text(json.dumps({"metadata": {"total_size": total_size}, "weight_map": weight_map}, indent=2))
+
+    def save_model_checkpoint(self, model_state_dict: dict[str, torch.Tensor], global_step: int, *, output_dir: Any = None,
+                              ignore_suffixes: Any = None) -> Path:
+        output_dir = Path(output_dir) if output_dir is not None else self._out_dir / f"step_{global_step}"
+        self.save_full_model({MODEL_KEY: model_state_dict}, output_dir)
+        skip = tuple(ignore_suffixes) if ignore_suffixes is not None else (*SUFFIXES_TO_NOT_COPY, "torchtune_config.yaml")
+        for f in self._ckpt_dir.iterdir():  # config, tokenizer, generation config ...: the directory is usable by HF tooling
+            if f.is_file() and not f.name.endswith(skip):
+                shutil.copy2(f, output_dir / f.name)
+        return output_dir
+
+
+def make_checkpointer(**kwargs: Any):
+    """HF-format checkpointer when ``checkpoint_dir`` is an HF model directory (has config.json), else the single-file
+    torchtune-key checkpointer (random init when no weights exist on disk — the build and GPU images have none)."""
+    d = kwargs.get("checkpoint_dir")
+    if d and (Path(str(d)) / LLAMA_3_2_CONFIG_RELPATH).exists():
+        return FullModelHFCheckpointer(**kwargs)
+    return TuneCheckpointer(**kwargs)

@@ -180,7 +180,7 @@ class Trainer:
             LOGGER.info(f"No checkpointer output dir provided. Resolved to: {self.cfg.checkpointer.output_dir!s}")
 
     def _setup_model(self) -> None:
-        from .checkpoint import TuneCheckpointer
+        from .checkpoint import make_checkpointer
         self._llama_config = copy.deepcopy(configllama3_2_1b)
         self._llama_config.update_from_speech_cfg(self.cfg.speech)
         overrides = self.cfg.get("model_overrides")  # test/bench hook: shrink the architecture, never used by conf/
@@ -188,7 +188,7 @@ class Trainer:
             for k in overrides:
                 setattr(self._llama_config, k, overrides[k])
         ck = {k: self.cfg.checkpointer[k] for k in self.cfg.checkpointer}
-        self.checkpointer = TuneCheckpointer(**ck, model_expectations=self._llama_config.checkpoint_expectations)
+        self.checkpointer = make_checkpointer(**ck, model_expectations=self._llama_config.checkpoint_expectations)
         self._ckpt_dict = self.checkpointer.load_checkpoint()
         self.model = setup_llama3_2_1b(cfg=self.cfg, llama_config=self._llama_config,
                                        model_state_dict=self._ckpt_dict.get(MODEL_KEY), dtype_default=self.dtype,

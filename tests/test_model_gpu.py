@@ -278,6 +278,44 @@ def test_bf16_mfma_shaped_model_matches_oracle(transposed_copies):
     assert l2.item() < loss.item()  # the step reduced the loss on the same batch
 
 
+def test_hf_format_checkpoint_loads_into_the_hip_model_and_matches_hf_llama(tmp_path):
+    """SURVEY.md §8f rank 3, end to end: a randomly initialised HF ``LlamaForCausalLM`` (built from a local config, no hub) is
+    written as an HF model directory (sharded safetensors + config.json), read back through ``FullModelHFCheckpointer`` (key map
+    and q/k row permutation) into the HIP model, whose fp32 logits must equal HF's own forward; the checkpoint the HIP model
+    then writes loads back into HF-Llama unchanged."""
+    import json
+    from safetensors.torch import load_file, save_file
+    from oracle import hf_crosscheck as hx
+    from ssi.checkpoint import FullModelHFCheckpointer
+    from ssi.constants import MODEL_KEY
+    from ssi.model import HipLlamaDecoder
+    params = dict(vocab_size=515, num_layers=2, num_heads=8, num_kv_heads=2, embed_dim=128, max_seq_len=64, intermediate_dim=256)
+    hf = hx.build_hf(params, hx.seeded_state_dict(params, 31))  # HF module holding HF-ordered weights
+    sd_hf = {k: v.detach().clone() for k, v in hf.state_dict().items() if k != "lm_head.weight" and "rotary" not in k}  # tied: one copy on disk
+    src = tmp_path / "hf"
+    src.mkdir()
+    keys = sorted(sd_hf)
+    save_file({k: sd_hf[k] for k in keys[: len(keys) // 2]}, str(src / "model-00001-of-00002.safetensors"), metadata={"format": "pt"})
+    save_file({k: sd_hf[k] for k in keys[len(keys) // 2:]}, str(src / "model-00002-of-00002.safetensors"), metadata={"format": "pt"})
+    (src / "config.json").write_text(json.dumps({"num_attention_heads": 8, "num_key_value_heads": 2, "hidden_size": 128,
+                                                 "num_hidden_layers": 2, "vocab_size": 515, "tie_word_embeddings": True}))
+    ck = FullModelHFCheckpointer(src, None, output_dir=tmp_path / "out")
+    model = HipLlamaDecoder(**params, dtype=torch.float32, device=DEV)
+    model.load_state_dict(ck.load_checkpoint()[MODEL_KEY])
+    model.set_num_output_chunks(0)
+    tokens = torch.randint(0, 515, (2, 40), generator=torch.Generator().manual_seed(32))
+    with torch.no_grad():
+        ref = hf(input_ids=tokens).logits
+        got = model(tokens=tokens.to(DEV)).float().cpu()
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    # save from the HIP model, reload into a fresh HF-Llama: bit-identical weights, same logits
+    step_dir = ck.save_model_checkpoint(model.state_dict(), 1)
+    written = {}
+    for f in sorted(step_dir.glob("*.safetensors")):
+        written.update(load_file(str(f)))
+    assert written.keys() == sd_hf.keys() and all(torch.equal(written[k], sd_hf[k]) for k in sd_hf)
+
+
 def test_full_size_step_properties():
     """BASELINE config A at full size (Llama-3.2-1B + 5000 DSUs, B=8, S=2048, bf16): size-independent properties.
     (1) random-init loss ~ ln V; (2) bitwise reproducibility of loss and gradients; (3) gradient accumulation is additive;
