@@ -81,6 +81,17 @@ int ssi_attn_bwd(const void* qkv, int64_t ld, const void* out, const void* dout,
                  float* delta, int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype,
                  void* stream);
 
+/* Packed rows (several documents per row; SURVEY.md §8f rank 1, the block-causal mask torchtune's padded_collate_packed builds
+ * from `seq_lens`, reference stub ssi/data/__init__.py:66-73,202-205): doc_start / doc_end are int32 [B*S]; for position s of
+ * row b, doc_start[b*S+s] is the first position and doc_end[b*S+s] one past the last position of the document holding s (both
+ * relative to the row, non-decreasing along it).  A query sees the keys doc_start <= key <= query.  Both NULL = plain causal
+ * attention (= ssi_attn_fwd / ssi_attn_bwd).  Key tiles outside the documents of a query block are skipped, not masked. */
+int ssi_attn_varlen_fwd(const void* qkv, int64_t ld, void* out, float* lse, const int32_t* doc_start, const int32_t* doc_end,
+                        int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype, void* stream);
+int ssi_attn_varlen_bwd(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
+                        float* delta, const int32_t* doc_start, const int32_t* doc_end, int64_t batch, int64_t seq,
+                        int n_heads, int n_kv, int head_dim, int dtype, void* stream);
+
 /* ---- K7  SwiGLU elementwise (torchtune FeedForward: w2(silu(w1 x) * w3 x)) ------------------------------------------ */
 /* gu: [rows, 2*inter] = [gate | up]; act[rows, inter] = silu(gate) * up */
 int ssi_swiglu_fwd(const void* gu, void* act, int64_t rows, int64_t inter, int dtype, void* stream);

@@ -113,6 +113,8 @@ class Attention(nn.Module):
             k = k.unsqueeze(3).expand(b, s, self.n_kv, rep, self.hd).flatten(2, 3)
             v = v.unsqueeze(3).expand(b, s, self.n_kv, rep, self.hd).flatten(2, 3)
         k, v = k.transpose(1, 2), v.transpose(1, 2)
+        if mask is not None and mask.dim() == 3:
+            mask = mask[:, None, :, :]  # [b, s, s] bool (True = attend), broadcast over heads as torchtune's MultiHeadAttention does
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=0.0, is_causal=mask is None)
         return self.output_proj(o.transpose(1, 2).contiguous().view(b, s, -1))
 

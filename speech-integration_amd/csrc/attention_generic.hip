@@ -3,14 +3,18 @@
 // (forward, dQ) or per key row (dK, dV); lanes stride over the other sequence axis with per-lane online softmax state
 // that is merged across the wave at the end.  Semantics: F.scaled_dot_product_attention(q, k, v, is_causal=True,
 // dropout_p=0) with k/v heads repeated n_heads/n_kv times (torchtune MultiHeadAttention).
+// Packed rows: doc_start[b*S + s] / doc_end[b*S + s] = first position / one past the last position of
+// the document that holds position s; a query then sees the keys doc_start <= j <= i only (torchtune's block-causal mask of
+// `padded_collate_packed`), a key is seen by the queries j <= i < doc_end.
 #include "common.cuh"
 
 int ssi_get_impl();
 bool ssi_attn_mfma_supported(int64_t ld, int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype);
-int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, int64_t batch, int64_t seq, int n_heads,
-                      int n_kv, void* stream);
+int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, const int32_t* doc_start, int64_t batch, int64_t seq,
+                      int n_heads, int n_kv, void* stream);
 int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
-                      float* delta, int64_t batch, int64_t seq, int n_heads, int n_kv, void* stream);
+                      float* delta, const int32_t* doc_start, const int32_t* doc_end, int64_t batch, int64_t seq, int n_heads,
+                      int n_kv, void* stream);
 
 template <typename T, int HD>
 __device__ __forceinline__ void load_row(const T* p, float (&r)[HD]) {
@@ -25,8 +29,8 @@ __device__ __forceinline__ void load_row(const T* p, float (&r)[HD]) {
 
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_fwd_generic(const T* __restrict__ qkv, int64_t ld, T* __restrict__ out,
-                                                        float* __restrict__ lse, int64_t batch, int64_t seq, int n_heads,
-                                                        int n_kv) {
+                                                        float* __restrict__ lse, const int32_t* __restrict__ doc_start,
+                                                        int64_t batch, int64_t seq, int n_heads, int n_kv) {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, h, i)
     if (w >= batch * n_heads * seq) return;
@@ -43,7 +47,8 @@ __global__ __launch_bounds__(256) void attn_fwd_generic(const T* __restrict__ qk
 #pragma unroll
     for (int d = 0; d < HD; ++d) o[d] = 0.f;
     float m = -INFINITY, l = 0.f;
-    for (int64_t j = lane; j <= i; j += 64) {
+    const int64_t j0 = doc_start ? doc_start[b * seq + i] : 0;  // packed rows: keys of the query's own document only
+    for (int64_t j = j0 + lane; j <= i; j += 64) {
         const T* krow = qkv + (b * seq + j) * ld + koff;
         const T* vrow = qkv + (b * seq + j) * ld + voff;
         float kr[HD];
@@ -96,8 +101,8 @@ __global__ __launch_bounds__(256) void attn_delta_generic(const T* __restrict__ 
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_generic(const T* __restrict__ qkv, int64_t ld, const T* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           T* __restrict__ dqkv, int64_t batch, int64_t seq, int n_heads,
-                                                           int n_kv) {
+                                                           T* __restrict__ dqkv, const int32_t* __restrict__ doc_start,
+                                                           int64_t batch, int64_t seq, int n_heads, int n_kv) {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= batch * n_heads * seq) return;
@@ -114,7 +119,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_generic(const T* __restrict__
 #pragma unroll
     for (int d = 0; d < HD; ++d) dq[d] = 0.f;
     const float L = lse[(b * n_heads + h) * seq + i], dl = delta[(b * n_heads + h) * seq + i];
-    for (int64_t j = lane; j <= i; j += 64) {
+    const int64_t j0 = doc_start ? doc_start[b * seq + i] : 0;
+    for (int64_t j = j0 + lane; j <= i; j += 64) {
         float r[HD];
         load_row<T, HD>(qkv + (b * seq + j) * ld + voff, r);
         float dp = 0.f;
@@ -141,8 +147,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_generic(const T* __restrict__
 template <typename T, int HD, bool DK>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_generic(const T* __restrict__ qkv, int64_t ld, const T* __restrict__ dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
-                                                            T* __restrict__ dqkv, int64_t batch, int64_t seq, int n_heads,
-                                                            int n_kv) {
+                                                            T* __restrict__ dqkv, const int32_t* __restrict__ doc_end,
+                                                            int64_t batch, int64_t seq, int n_heads, int n_kv) {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= batch * n_kv * seq) return;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_generic(const T* __restrict_
     load_row<T, HD>(qkv + (b * seq + j) * ld + koff, kr);
 #pragma unroll
     for (int d = 0; d < HD; ++d) acc[d] = 0.f;
-    const int64_t nq = seq - j;  // queries i = j .. seq-1
+    const int64_t nq = (doc_end ? doc_end[b * seq + j] : seq) - j;  // queries i = j .. end of the key's document - 1
     for (int64_t e = lane; e < nq * rep; e += 64) {
         const int64_t i = j + e / rep;
         const int h = kvh * rep + (int)(e % rep);
@@ -208,44 +214,56 @@ static int attn_check(const void* qkv, int64_t ld, int64_t batch, int64_t seq, i
     return SSI_OK;
 }
 
-extern "C" int ssi_attn_fwd(const void* qkv, int64_t ld, void* out, float* lse, int64_t batch, int64_t seq, int n_heads,
-                            int n_kv, int head_dim, int dtype, void* stream) {
+extern "C" int ssi_attn_varlen_fwd(const void* qkv, int64_t ld, void* out, float* lse, const int32_t* doc_start, const int32_t* doc_end,
+                                   int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype, void* stream) {
     if (int rc = attn_check(qkv, ld, batch, seq, n_heads, n_kv, head_dim)) return rc;
-    SSI_CHECK_ARG(out && lse);
+    SSI_CHECK_ARG(out && lse && ((doc_start == nullptr) == (doc_end == nullptr)));
     if (batch * seq == 0) return SSI_OK;
     const bool fast = ssi_attn_mfma_supported(ld, batch, seq, n_heads, n_kv, head_dim, dtype);
     if ((ssi_get_impl() == SSI_IMPL_MFMA || ssi_get_impl() == SSI_IMPL_MFMA_WG8) && !fast) { ssi_set_error("ssi_attn_fwd: MFMA path forced but unsupported shape"); return SSI_ERR_UNSUPPORTED; }
-    if (fast && ssi_get_impl() != SSI_IMPL_GENERIC) return ssi_attn_fwd_mfma(qkv, ld, out, lse, batch, seq, n_heads, n_kv, stream);
+    if (fast && ssi_get_impl() != SSI_IMPL_GENERIC) return ssi_attn_fwd_mfma(qkv, ld, out, lse, doc_start, batch, seq, n_heads, n_kv, stream);
     const int64_t nw = batch * n_heads * seq;
     SSI_DISPATCH_DTYPE(dtype, ATTN_HD_SWITCH(head_dim, hipLaunchKernelGGL((attn_fwd_generic<T, HD>), dim3((unsigned)ssi_cdiv(nw, 4)),
                                                                          dim3(256), 0, (hipStream_t)stream, (const T*)qkv, ld,
-                                                                         (T*)out, lse, batch, seq, n_heads, n_kv)));
+                                                                         (T*)out, lse, doc_start, batch, seq, n_heads, n_kv)));
     SSI_LAUNCH_CHECK();
     return SSI_OK;
 }
 
-extern "C" int ssi_attn_bwd(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
-                            float* delta, int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype,
-                            void* stream) {
+extern "C" int ssi_attn_varlen_bwd(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
+                                   float* delta, const int32_t* doc_start, const int32_t* doc_end, int64_t batch, int64_t seq,
+                                   int n_heads, int n_kv, int head_dim, int dtype, void* stream) {
     if (int rc = attn_check(qkv, ld, batch, seq, n_heads, n_kv, head_dim)) return rc;
-    SSI_CHECK_ARG(out && dout && lse && dqkv && delta);
+    SSI_CHECK_ARG(out && dout && lse && dqkv && delta && ((doc_start == nullptr) == (doc_end == nullptr)));
     if (batch * seq == 0) return SSI_OK;
     const bool fast = ssi_attn_mfma_supported(ld, batch, seq, n_heads, n_kv, head_dim, dtype);
     if ((ssi_get_impl() == SSI_IMPL_MFMA || ssi_get_impl() == SSI_IMPL_MFMA_WG8) && !fast) { ssi_set_error("ssi_attn_bwd: MFMA path forced but unsupported shape"); return SSI_ERR_UNSUPPORTED; }
     if (fast && ssi_get_impl() != SSI_IMPL_GENERIC)
-        return ssi_attn_bwd_mfma(qkv, ld, out, dout, lse, dqkv, delta, batch, seq, n_heads, n_kv, stream);
+        return ssi_attn_bwd_mfma(qkv, ld, out, dout, lse, dqkv, delta, doc_start, doc_end, batch, seq, n_heads, n_kv, stream);
     auto st = (hipStream_t)stream;
     const int64_t nq = batch * n_heads * seq, nk = batch * n_kv * seq;
     SSI_DISPATCH_DTYPE(dtype, ATTN_HD_SWITCH(head_dim, {
         hipLaunchKernelGGL((attn_delta_generic<T, HD>), dim3((unsigned)ssi_cdiv(nq, 256)), dim3(256), 0, st, (const T*)out,
                            (const T*)dout, delta, batch, seq, n_heads);
         hipLaunchKernelGGL((attn_bwd_dq_generic<T, HD>), dim3((unsigned)ssi_cdiv(nq, 4)), dim3(256), 0, st, (const T*)qkv, ld,
-                           (const T*)dout, lse, delta, (T*)dqkv, batch, seq, n_heads, n_kv);
+                           (const T*)dout, lse, delta, (T*)dqkv, doc_start, batch, seq, n_heads, n_kv);
         hipLaunchKernelGGL((attn_bwd_dkv_generic<T, HD, true>), dim3((unsigned)ssi_cdiv(nk, 4)), dim3(256), 0, st, (const T*)qkv,
-                           ld, (const T*)dout, lse, delta, (T*)dqkv, batch, seq, n_heads, n_kv);
+                           ld, (const T*)dout, lse, delta, (T*)dqkv, doc_end, batch, seq, n_heads, n_kv);
         hipLaunchKernelGGL((attn_bwd_dkv_generic<T, HD, false>), dim3((unsigned)ssi_cdiv(nk, 4)), dim3(256), 0, st, (const T*)qkv,
-                           ld, (const T*)dout, lse, delta, (T*)dqkv, batch, seq, n_heads, n_kv);
+                           ld, (const T*)dout, lse, delta, (T*)dqkv, doc_end, batch, seq, n_heads, n_kv);
     }));
     SSI_LAUNCH_CHECK();
     return SSI_OK;
+}
+
+
+extern "C" int ssi_attn_fwd(const void* qkv, int64_t ld, void* out, float* lse, int64_t batch, int64_t seq, int n_heads,
+                            int n_kv, int head_dim, int dtype, void* stream) {
+    return ssi_attn_varlen_fwd(qkv, ld, out, lse, nullptr, nullptr, batch, seq, n_heads, n_kv, head_dim, dtype, stream);
+}
+
+extern "C" int ssi_attn_bwd(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
+                            float* delta, int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype,
+                            void* stream) {
+    return ssi_attn_varlen_bwd(qkv, ld, out, dout, lse, dqkv, delta, nullptr, nullptr, batch, seq, n_heads, n_kv, head_dim, dtype, stream);
 }

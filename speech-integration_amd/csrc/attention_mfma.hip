@@ -119,7 +119,8 @@ __device__ __forceinline__ void dma_kv_tile(const bf16_t* kbase, const bf16_t* v
 // =====================================================================================================================
 // grid.x = B * KV * (S / (32 * QPW)),  QPW = 4 / rep q-blocks per workgroup; wave w: head kvh*rep + w % rep, q-block w / rep
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t ld, bf16_t* __restrict__ out,
-                                                       float* __restrict__ lse, int S, int H, int KV) {
+                                                       float* __restrict__ lse, const int32_t* __restrict__ doc_start, int S, int H,
+                                                       int KV) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 2 * 8192];  // ring of 3 x [K | V][64][64] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep = H / KV, qpw = 4 / rep;
@@ -136,6 +137,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const int64_t row0 = (int64_t)b * S;
     const bf16_t* kbase = qkv + row0 * ld + (int64_t)H * HD + (int64_t)kvh * HD;
     const bf16_t* vbase = kbase + (int64_t)KV * HD;
+    // packed rows: a query sees keys doc_start <= key <= query.  doc_start is non-decreasing along a row, so the first key
+    // tile any row of the workgroup / wave needs, and whether a tile needs the document mask, follow from the end rows.
+    const int qg_ = q0 + (lane & 31);
+    const int ds = doc_start ? doc_start[row0 + qg_] : 0;                       // this lane's query
+    const int ds_lo = doc_start ? doc_start[row0 + q0] : 0;                     // first row of the wave
+    const int ds_hi = doc_start ? doc_start[row0 + q0 + 31] : 0;                // last row of the wave
+    const int t_first = doc_start ? doc_start[row0 + qgrp * qpw * 32] / 64 : 0;  // first tile of the workgroup
 
     // Q as the B operand of S^T = K Q^T, pre-scaled by 1/sqrt(64) = 2^-3 (exact in bf16)
     bf16x8 qf[4];
@@ -153,8 +161,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const int qg = q0 + (lane & 31);
 
     // ring of 3 tile slots filled by LDS-DMA two tiles ahead (4 requests per wave per tile)
-    dma_kv_tile<SWZ_ROW, SWZ_TR>(kbase, vbase, ld, 0, smem, wave, lane);
-    if (nt > 1) dma_kv_tile<SWZ_ROW, SWZ_TR>(kbase, vbase, ld, 1, smem + 16384, wave, lane);
+    dma_kv_tile<SWZ_ROW, SWZ_TR>(kbase, vbase, ld, t_first, smem, wave, lane);
+    if (t_first + 1 < nt) dma_kv_tile<SWZ_ROW, SWZ_TR>(kbase, vbase, ld, t_first + 1, smem + 16384, wave, lane);
     auto tile_step = [&](int t, auto buf_c) {
         constexpr int BUF = decltype(buf_c)::value;  // compile-time ring slot: LDS addresses = hoisted lane base + immediate
         const char* kt = smem + BUF * 16384;
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         ring_barrier();  // everybody's pieces landed; the slot of tile t-1 is free again
         if (t + 2 < nt) dma_kv_tile<SWZ_ROW, SWZ_TR>(kbase, vbase, ld, t + 2, smem + ((BUF + 2) % 3) * 16384, wave, lane);
         const int k0 = t * 64;
-        if (k0 <= q0 + 31) {  // wave-uniform: this tile intersects the causal range of the wave's rows
+        if (k0 <= q0 + 31 && k0 + 63 >= ds_lo) {  // wave-uniform: this tile intersects the visible range of the wave's rows
             f32x16 sacc[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -174,12 +182,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                 for (int ks = 0; ks < 4; ++ks)
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(kt, kb * 32, ks, lane), qf[ks], sacc[kb], 0, 0, 0);
             }
-            if (k0 + 63 > q0) {  // diagonal tile: mask keys beyond the query
+            if (k0 + 63 > q0 || k0 < ds_hi) {  // edge tile: mask keys beyond the query or before its document
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (k0 + kb * 32 + rowmap(r, h) > qg) sacc[kb][r] = -INFINITY;
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + kb * 32 + rowmap(r, h);
+                        if (key > qg || key < ds) sacc[kb][r] = -INFINITY;
+                    }
             }
             float mx = sacc[0][0];
 #pragma unroll
@@ -188,8 +198,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mn = fmaxf(m, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
-            const float mb = mn * LOG2E;
+            // a row whose document starts after this tile has seen no key yet (m = mn = -inf): keep its state finite
+            const float mref = mn == -INFINITY ? 0.f : mn;
+            const float alpha = __builtin_amdgcn_exp2f((m - mref) * LOG2E);
+            const float mb = mref * LOG2E;
             float rs = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
             }
         }
     };
-    for (int t = 0; t < nt; t += 3) {
+    for (int t = t_first; t < nt; t += 3) {
         tile_step(t, std::integral_constant<int, 0>{});
         if (t + 1 < nt) tile_step(t + 1, std::integral_constant<int, 1>{});
         if (t + 2 < nt) tile_step(t + 2, std::integral_constant<int, 2>{});
@@ -260,8 +272,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // =====================================================================================================================
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                          const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S,
-                                                          int H, int KV) {
+                                                          const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
+                                                          const int32_t* __restrict__ doc_start, int S, int H, int KV) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 2 * 8192];  // ring of 3 x [K | V][64][64] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep = H / KV, qpw = 4 / rep;
@@ -277,6 +289,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     const bf16_t* kbase = qkv + row0 * ld + (int64_t)H * HD + (int64_t)kvh * HD;
     const bf16_t* vbase = kbase + (int64_t)KV * HD;
     const int qg = q0 + (lane & 31);
+    // packed rows: see attn_fwd_kernel
+    const int ds = doc_start ? doc_start[row0 + qg] : 0;
+    const int ds_lo = doc_start ? doc_start[row0 + q0] : 0;
+    const int ds_hi = doc_start ? doc_start[row0 + q0 + 31] : 0;
+    const int t_first = doc_start ? doc_start[row0 + qgrp * qpw * 32] / 64 : 0;
 
     bf16x8 qf[4], dof[4];
     {
@@ -296,8 +313,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
-    dma_kv_tile<SWZ_ROW, SWZ_ROW>(kbase, vbase, ld, 0, smem, wave, lane);
-    if (nt > 1) dma_kv_tile<SWZ_ROW, SWZ_ROW>(kbase, vbase, ld, 1, smem + 16384, wave, lane);
+    dma_kv_tile<SWZ_ROW, SWZ_ROW>(kbase, vbase, ld, t_first, smem, wave, lane);
+    if (t_first + 1 < nt) dma_kv_tile<SWZ_ROW, SWZ_ROW>(kbase, vbase, ld, t_first + 1, smem + 16384, wave, lane);
     auto tile_step = [&](int t, auto buf_c) {
         constexpr int BUF = decltype(buf_c)::value;
         const char* kt = smem + BUF * 16384;
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         ring_barrier();  // everybody's pieces landed; the slot of tile t-1 is free again
         if (t + 2 < nt) dma_kv_tile<SWZ_ROW, SWZ_ROW>(kbase, vbase, ld, t + 2, smem + ((BUF + 2) % 3) * 16384, wave, lane);
         const int k0 = t * 64;
-        if (k0 <= q0 + 31) {
+        if (k0 <= q0 + 31 && k0 + 63 >= ds_lo) {
             f32x16 sacc[2], pacc[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -319,13 +336,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                     pacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(vt, kb * 32, ks, lane), dof[ks], pacc[kb], 0, 0, 0);
                 }
             }
-            if (k0 + 63 > q0) {  // diagonal tile: keys beyond the query contribute nothing
+            if (k0 + 63 > q0 || k0 < ds_hi) {  // edge tile: keys beyond the query or before its document contribute nothing
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float p = __builtin_amdgcn_exp2f(sacc[kb][r] * LOG2E);
-                        if (k0 + kb * 32 + rowmap(r, h) > qg) p = 0.f;
+                        const int key = k0 + kb * 32 + rowmap(r, h);
+                        if (key > qg || key < ds) p = 0.f;
                         sacc[kb][r] = p * pacc[kb][r];  // dS^T (the 1/sqrt(d) factor is applied once at the end)
                     }
             } else {
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
             }
         }
     };
-    for (int t = 0; t < nt; t += 3) {
+    for (int t = t_first; t < nt; t += 3) {
         tile_step(t, std::integral_constant<int, 0>{});
         if (t + 1 < nt) tile_step(t + 1, std::integral_constant<int, 1>{});
         if (t + 2 < nt) tile_step(t + 2, std::integral_constant<int, 2>{});
@@ -371,8 +389,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // output element.
 __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                           const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S,
-                                                           int H, int KV) {
+                                                           const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
+                                                           const int32_t* __restrict__ doc_end, int S, int H, int KV) {
     // ring of RING step buffers: [Q tile 4 KiB | dO tile 4 KiB | lse 128 B | delta 128 B]; requests run RING-1 steps ahead
     constexpr int SB = 8192 + 256;
     constexpr int RING = DKV_RING;
@@ -408,8 +426,15 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
-    const int qb_first = kgrp * 4;          // first 32-query tile that sees any key of the group
-    const int per_head = S / 32 - qb_first;  // tiles per query head
+    // packed rows: key k is seen by the queries k <= q < doc_end[k] (doc_end is non-decreasing along a row): the tile loop stops
+    // at the end of the document of the group's last key, a tile needs the document mask iff it reaches past the end of the
+    // document of the wave's first key, and is dead for the wave from the end of the document of its last key on.
+    const int de = doc_end ? doc_end[row0 + kg] : S;                      // this lane's key
+    const int de_lo = doc_end ? doc_end[row0 + key0] : S;                 // first key of the wave
+    const int de_hi = doc_end ? doc_end[row0 + key0 + 31] : S;            // last key of the wave
+    const int q_end = doc_end ? doc_end[row0 + kgrp * 128 + 127] : S;     // last key of the group
+    const int qb_first = kgrp * 4;                       // first 32-query tile that sees any key of the group
+    const int per_head = (q_end + 31) / 32 - qb_first;   // tiles per query head
     const int n_steps = per_head * rep;
     // step -> (head of the group, query tile); each wave moves one 1-KiB piece of Q and one of dO per step
     auto issue = [&](int step) {
@@ -444,7 +469,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
             if (step + RING - 2 < n_steps) issue(step + RING - 2);
             if (step + RING - 1 < n_steps) issue(step + RING - 1);
         }
-        if (q0 + 31 < key0) return;  // wave-uniform: every key of this wave is in the future of every query of the tile
+        if (q0 + 31 < key0 || q0 >= de_hi) return;  // wave-uniform: no query of the tile sees any key of this wave
         f32x16 sacc, pacc;  // rows = queries q0 + rowmap(r, h): row constants come in runs of 4
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -458,11 +483,12 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(qt, 0, ks, lane), kf[ks], sacc, 0, 0, 0);
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(dt, 0, ks, lane), vf[ks], pacc, 0, 0, 0);
         }
-        if (q0 < key0 + 32) {  // diagonal tile: keys beyond the query contribute nothing
+        if (q0 < key0 + 32 || q0 + 31 >= de_lo) {  // edge tile: keys beyond the query or of an earlier document contribute nothing
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float p = __builtin_amdgcn_exp2f(sacc[r] * -LOG2E);
-                if (kg > q0 + rowmap(r, h)) p = 0.f;
+                const int q = q0 + rowmap(r, h);
+                if (kg > q || q >= de) p = 0.f;
                 sacc[r] = p;
                 pacc[r] *= p;
             }
@@ -527,18 +553,19 @@ bool ssi_attn_mfma_supported(int64_t ld, int64_t batch, int64_t seq, int n_heads
     return true;
 }
 
-int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, int64_t batch, int64_t seq, int n_heads, int n_kv,
-                      void* stream) {
+int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, const int32_t* doc_start, int64_t batch, int64_t seq,
+                      int n_heads, int n_kv, void* stream) {
     const int rep = n_heads / n_kv, qpw = 4 / rep;
     const unsigned grid = (unsigned)(batch * n_kv * (seq / (32 * qpw)));
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)out, lse,
-                       (int)seq, n_heads, n_kv);
+                       doc_start, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
     return SSI_OK;
 }
 
 int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
-                      int64_t batch, int64_t seq, int n_heads, int n_kv, void* stream) {
+                      const int32_t* doc_start, const int32_t* doc_end, int64_t batch, int64_t seq, int n_heads, int n_kv,
+                      void* stream) {
     auto st = (hipStream_t)stream;
     const int rep = n_heads / n_kv, qpw = 4 / rep;
     const int64_t rows = batch * seq;
@@ -546,10 +573,10 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
                        (const bf16_t*)dout, delta, rows, (int)seq, n_heads);
     SSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * n_kv * (seq / (32 * qpw)))), dim3(256), 0, st, (const bf16_t*)qkv,
-                       ld, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, (int)seq, n_heads, n_kv);
+                       ld, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_start, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(batch * n_kv * (seq / 128))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
-                       (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, (int)seq, n_heads, n_kv);
+                       (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
     return SSI_OK;
 }

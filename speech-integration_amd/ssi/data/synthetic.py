@@ -102,3 +102,18 @@ def setup_synthetic_data(n_samples: int, seq_len: int, batch_size: int, n_dsus: 
     loader = DataLoader(ds, batch_size=batch_size, sampler=sampler, drop_last=drop_last,
                         collate_fn=partial(padded_collate_sft, padding_idx=ds.pad_id, ignore_idx=CROSS_ENTROPY_IGNORE_IDX))
     return loader, sampler
+
+
+def synthetic_packed_batch(batch_size: int, seq_len: int, n_dsus: int = 5000, seed: int = SEED, rank: int = 0,
+                           doc_len: int = 1100, kind: str = "sft") -> dict[str, Any]:
+    """``batch_size`` packs of ``seq_len`` tokens filled with MLS-shaped synthetic documents of 0.4-1.0 x ``doc_len`` tokens
+    (BASELINE config E: documents of ~600-1100 tokens in rows of 8192), in the format of ``padded_collate_packed``."""
+    from .packed import PackedDataset, padded_collate_packed
+    n_docs = batch_size * (seq_len // max(1, int(0.4 * doc_len)) + 2)
+    ds = SyntheticDSUDataset(n_docs, doc_len, n_dsus, fixed_len=False, kind=kind)
+    ds.set_epoch(seed + rank)
+    docs = ({"tokens": d["tokens"], "labels": d["labels"]} for d in (ds[i] for i in range(n_docs)))
+    packs = PackedDataset(docs, max_seq_len=seq_len, padding_idx=ds.pad_id, max_packs=batch_size)
+    if len(packs) < batch_size:
+        raise RuntimeError("not enough synthetic documents to fill the packs")
+    return padded_collate_packed([packs[i] for i in range(batch_size)])

@@ -67,9 +67,10 @@ def compute_loss(batch: dict[str, Tensor], model, loss_fn: Callable) -> Tensor:
     labels = batch["labels"]
     ignore_index = loss_fn.ignore_index
     labels = torch.hstack((labels[..., 1:], torch.full_like(labels[..., -1:], ignore_index)))  # new tensor: batch untouched
-    if (hasattr(model, "fused_loss") and isinstance(loss_fn, CEWithChunkedOutputLoss) and batch.get("mask") is None
-            and batch.get("input_pos") is None and batch.get("encoder_input") is None):
-        return model.fused_loss(batch["tokens"], labels, ignore_index)
+    if (hasattr(model, "fused_loss") and isinstance(loss_fn, CEWithChunkedOutputLoss) and batch.get("encoder_input") is None
+            and (batch.get("mask") is None or batch.get("input_pos") is not None)):
+        # packed batches (ssi/data/packed.py) carry input_pos: block-causal attention, per-document RoPE positions
+        return model.fused_loss(batch["tokens"], labels, ignore_index, input_pos=batch.get("input_pos"))
     logits = model(
         tokens=batch["tokens"],
         mask=batch.get("mask"),

@@ -307,8 +307,32 @@ class HipLlamaDecoder(nn.Module):
         return _align(seq, g)
 
     # ---- forward: decoder stack --------------------------------------------------------------------------------------
-    def _forward_hidden(self, tokens: Tensor, save: bool) -> Tensor:
+    @staticmethod
+    def _document_ranges(input_pos: Tensor) -> tuple[Tensor, Tensor, Tensor]:
+        """Packed rows (torchtune ``PackedDataset``: ``input_pos`` restarts at 0 with every document of a row) -> int32 [B*S]
+        (positions, doc_start, doc_end): a query attends to the keys doc_start <= key <= query of its own row, which is the
+        block-causal mask ``padded_collate_packed`` builds from ``seq_lens``.  The padding tail of a pack continues the last
+        document's positions and so joins it: no real query sees those keys (causal) and their labels are ignored."""
+        B, S = input_pos.shape
+        idx = torch.arange(S, device=input_pos.device, dtype=torch.int64).expand(B, S)
+        is_start = input_pos == 0
+        is_start[:, 0] = True
+        doc_start = torch.where(is_start, idx, torch.zeros_like(idx)).cummax(dim=1).values
+        nxt = torch.where(is_start, idx, torch.full_like(idx, S))
+        nxt = torch.cat([nxt[:, 1:], torch.full_like(nxt[:, :1], S)], dim=1)  # first document start strictly after s
+        doc_end = nxt.flip(1).cummin(dim=1).values.flip(1)
+        as32 = lambda t: t.to(torch.int32).reshape(-1).contiguous()  # noqa: E731
+        return as32(input_pos), as32(doc_start), as32(doc_end)
+
+    def _forward_hidden(self, tokens: Tensor, save: bool, input_pos: Optional[Tensor] = None) -> Tensor:
         B, S = tokens.shape
+        pos = ds = de = None
+        if input_pos is not None:
+            if input_pos.shape != tokens.shape:
+                raise ValueError("input_pos must have the shape of tokens")
+            if int(input_pos.max()) >= self._rope.shape[0]:
+                raise ValueError("input_pos exceeds the RoPE cache")
+            pos, ds, de = self._document_ranges(input_pos.to(tokens.device))
         T, D, I = B * S, self.embed_dim, self.intermediate_dim
         H, KV, hd, dt, A = self.num_heads, self.num_kv_heads, self.head_dim, self.dtype, self._arena
         if S > self._rope.shape[0]:
@@ -324,10 +348,10 @@ class HipLlamaDecoder(nn.Module):
             ops.rmsnorm_fwd(h, self._view(f"L{l}.sa_norm"), xn1, rstd1, self.norm_eps)
             qkv = A.get(f"qkv.{sfx}", (T, self.qkv_dim), dt)
             ops.gemm(GEMM_NT, xn1, self._view(f"L{l}.wqkv"), qkv)
-            ops.rope_(qkv, S, H + KV, hd, self._rope)
+            ops.rope_(qkv, S, H + KV, hd, self._rope, positions=pos)
             att = A.get(f"att.{sfx}", (T, H * hd), dt)
             lse = A.get(f"lse.{sfx}", (B * H * S,), torch.float32)
-            ops.attn_fwd(qkv, att, lse, B, S, H, KV, hd)
+            ops.attn_fwd(qkv, att, lse, B, S, H, KV, hd, ds, de)
             hmid = A.get(f"hmid.{sfx}", (T, D), dt)
             ops.gemm(GEMM_NT, att, self._view(f"L{l}.wo"), hmid, residual=h)
             xn2 = A.get(f"xn2.{sfx}", (T, D), dt)
@@ -345,7 +369,7 @@ class HipLlamaDecoder(nn.Module):
         ops.rmsnorm_fwd(h, self.norm.scale, hn, rstdf, self.norm_eps)
         if save:
             self._fwd_generation += 1
-            self._saved = {"tok": tok, "B": B, "S": S, "gen": self._fwd_generation}
+            self._saved = {"tok": tok, "B": B, "S": S, "gen": self._fwd_generation, "pos": pos, "ds": ds, "de": de}
         return hn
 
     # ---- backward: decoder stack -------------------------------------------------------------------------------------
@@ -355,6 +379,7 @@ class HipLlamaDecoder(nn.Module):
             raise RuntimeError("HipLlamaDecoder: backward called for a forward whose activations were overwritten; "
                                "run backward before the next training forward")
         B, S, tok = sv["B"], sv["S"], sv["tok"]
+        pos, ds, de = sv["pos"], sv["ds"], sv["de"]
         T, D, I = B * S, self.embed_dim, self.intermediate_dim
         H, KV, hd, dt, A = self.num_heads, self.num_kv_heads, self.head_dim, self.dtype, self._arena
         L = self.num_layers
@@ -412,8 +437,8 @@ class HipLlamaDecoder(nn.Module):
             wgrad(dhmid, att, f"L{l}.wo")
             dqkv = A.get("dqkv", (T, self.qkv_dim), dt)
             delta = A.get("delta", (B * H * S,), torch.float32)
-            ops.attn_bwd(qkv, att, datt, A.get(f"lse.{l}", (B * H * S,), torch.float32), dqkv, delta, B, S, H, KV, hd)
-            ops.rope_(dqkv, S, H + KV, hd, self._rope, inverse=True)
+            ops.attn_bwd(qkv, att, datt, A.get(f"lse.{l}", (B * H * S,), torch.float32), dqkv, delta, B, S, H, KV, hd, ds, de)
+            ops.rope_(dqkv, S, H + KV, hd, self._rope, inverse=True, positions=pos)
             dgrad(dqkv, f"L{l}.wqkv", dxn)
             wgrad(dqkv, xn1, f"L{l}.wqkv")
             ops.rmsnorm_bwd(dxn, h_in, self._view(f"L{l}.sa_norm"), A.get(f"rstd1.{l}", (T,), torch.float32), dhmid, dh,
@@ -448,22 +473,26 @@ class HipLlamaDecoder(nn.Module):
 
     # ---- public API --------------------------------------------------------------------------------------------------
     def _check_inputs(self, tokens: Tensor, mask, encoder_input, encoder_mask, input_pos) -> Tensor:
-        if mask is not None or encoder_input is not None or encoder_mask is not None or input_pos is not None:
-            raise NotImplementedError("only tokens= is supported: the reference's collate emits no mask/input_pos "
-                                      "(ssi/data/__init__.py:199) and has no encoder inputs")
+        if encoder_input is not None or encoder_mask is not None:
+            raise NotImplementedError("no encoder inputs: the reference's model is decoder-only (ssi/model.py:34)")
+        if mask is not None and input_pos is None:
+            raise NotImplementedError("a dense attention mask is never materialised: packed batches pass input_pos, from which "
+                                      "the block-causal mask follows (ssi/data/packed.py)")
+        # mask together with input_pos (torchtune's padded_collate_packed emits both): the block-causal structure is re-derived
+        # from input_pos; the dense [B, S, S] tensor itself is not read
         if tokens.dim() != 2 or tokens.dtype != torch.int64:
             raise ValueError("tokens must be an int64 tensor of shape [batch, seq]")
         if not tokens.is_cuda:
             raise _lib.HipLibraryError("tokens must live on the GPU (no CPU fallback)")
         return tokens
 
-    def forward_hidden(self, tokens: Tensor) -> Tensor:
+    def forward_hidden(self, tokens: Tensor, input_pos: Optional[Tensor] = None) -> Tensor:
         """Final-normed hidden states [B, S, D] (autograd-aware)."""
         B, S = tokens.shape
         if torch.is_grad_enabled() and self.training:
-            hn = _DecoderFn.apply(self, tokens, self._anchor)
+            hn = _DecoderFn.apply(self, tokens, self._anchor, input_pos)
         else:
-            hn = self._forward_hidden(tokens, save=False)
+            hn = self._forward_hidden(tokens, save=False, input_pos=input_pos)
         return hn.view(B, S, self.embed_dim)
 
     def forward(self, tokens: Tensor, mask=None, encoder_input=None, encoder_mask=None, input_pos=None):
@@ -471,7 +500,7 @@ class HipLlamaDecoder(nn.Module):
         SURVEY.md Appendix A.4); else one fp32 [B, S, V] tensor — as torchtune's ``TransformerDecoder.forward``."""
         tokens = self._check_inputs(tokens, mask, encoder_input, encoder_mask, input_pos)
         B, S = tokens.shape
-        hn = self.forward_hidden(tokens).view(B * S, self.embed_dim)
+        hn = self.forward_hidden(tokens, input_pos).view(B * S, self.embed_dim)
         if torch.is_grad_enabled() and self.training:
             logits = _HeadLogitsFn.apply(self, hn, self._anchor)
         else:
@@ -481,20 +510,25 @@ class HipLlamaDecoder(nn.Module):
             return list(logits.chunk(self.num_output_chunks, dim=1))
         return logits.float()
 
-    def fused_loss(self, tokens: Tensor, shifted_labels: Tensor, ignore_index: int = CROSS_ENTROPY_IGNORE_IDX) -> Tensor:
+    def fused_loss(self, tokens: Tensor, shifted_labels: Tensor, ignore_index: int = CROSS_ENTROPY_IGNORE_IDX,
+                   input_pos: Optional[Tensor] = None) -> Tensor:
         """Mean NLL over non-ignored (already shifted) labels with the LM head + CE fused: equals
-        ``CEWithChunkedOutputLoss()(model(tokens), shifted_labels)`` of the reference for any chunk count."""
-        tokens = self._check_inputs(tokens, None, None, None, None)
+        ``CEWithChunkedOutputLoss()(model(tokens, input_pos=...), shifted_labels)`` of the reference for any chunk count.
+        ``input_pos`` ([B, S], restarting at 0 with every document): packed rows, block-causal attention."""
+        tokens = self._check_inputs(tokens, None, None, None, input_pos)
         B, S = tokens.shape
         Sp = self.padded_seq_len(B, S)
         if Sp != S:
             pad_t = torch.zeros(B, Sp - S, dtype=tokens.dtype, device=tokens.device)
             tokens = torch.cat([tokens, pad_t], dim=1)
             shifted_labels = torch.cat([shifted_labels, torch.full_like(pad_t, ignore_index)], dim=1)
+            if input_pos is not None:  # the tail continues the last document (as PackedDataset pads a pack)
+                cont = input_pos[:, -1:].to(tokens.device) + torch.arange(1, Sp - S + 1, device=tokens.device)
+                input_pos = torch.cat([input_pos.to(tokens.device), cont.clamp_(max=self._rope.shape[0] - 1)], dim=1)
         labels = shifted_labels.reshape(-1).contiguous()
         if torch.is_grad_enabled() and self.training:
-            return _FusedLossFn.apply(self, tokens, labels, ignore_index, self._anchor)
-        hn = self._forward_hidden(tokens, save=False)
+            return _FusedLossFn.apply(self, tokens, labels, ignore_index, self._anchor, input_pos)
+        hn = self._forward_hidden(tokens, save=False, input_pos=input_pos)
         return self._ce_forward(hn, labels, ignore_index, write_grad=False)[0]
 
     def _ce_forward(self, hn: Tensor, labels: Tensor, ignore_index: int, write_grad: bool) -> tuple[Tensor, Tensor, Tensor]:
@@ -509,15 +543,15 @@ class HipLlamaDecoder(nn.Module):
 
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model: HipLlamaDecoder, tokens: Tensor, anchor: Tensor) -> Tensor:
-        hn = model._forward_hidden(tokens, save=True)
+    def forward(ctx, model: HipLlamaDecoder, tokens: Tensor, anchor: Tensor, input_pos: Optional[Tensor] = None) -> Tensor:
+        hn = model._forward_hidden(tokens, save=True, input_pos=input_pos)
         ctx.model, ctx.gen = model, model._fwd_generation
         return hn
 
     @staticmethod
     def backward(ctx, d_hn: Tensor):
         ctx.model._backward_hidden(d_hn.contiguous(), ctx.gen)
-        return None, None, torch.zeros_like(ctx.model._anchor)
+        return None, None, torch.zeros_like(ctx.model._anchor), None
 
 
 class _HeadLogitsFn(torch.autograd.Function):
@@ -542,8 +576,9 @@ class _FusedLossFn(torch.autograd.Function):
     gradient buffer (so ``p.grad`` is populated exactly as after ``loss.backward()`` in the reference)."""
 
     @staticmethod
-    def forward(ctx, model: HipLlamaDecoder, tokens: Tensor, labels: Tensor, ignore_index: int, anchor: Tensor) -> Tensor:
-        hn = model._forward_hidden(tokens, save=True)
+    def forward(ctx, model: HipLlamaDecoder, tokens: Tensor, labels: Tensor, ignore_index: int, anchor: Tensor,
+                input_pos: Optional[Tensor] = None) -> Tensor:
+        hn = model._forward_hidden(tokens, save=True, input_pos=input_pos)
         loss, stats, dlogits = model._ce_forward(hn, labels, ignore_index, write_grad=True)
         ctx.model, ctx.gen = model, model._fwd_generation
         ctx.save_for_backward(hn, stats, dlogits)
@@ -557,7 +592,7 @@ class _FusedLossFn(torch.autograd.Function):
         alpha = (grad_out.to(torch.float32).reshape(1) / stats[2:3]).contiguous()
         d_hn = m._head_backward(dlogits, hn, alpha)
         m._backward_hidden(d_hn, ctx.gen)
-        return None, None, None, None, torch.zeros_like(m._anchor)
+        return None, None, None, None, torch.zeros_like(m._anchor), None
 
 
 # --------------------------------------------------------------------------------------------------------------------

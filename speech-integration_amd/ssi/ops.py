@@ -4,6 +4,7 @@ pointers and the current HIP stream across the ABI, no torch compute ops.  Every
 from __future__ import annotations
 
 import torch
+from typing import Optional
 from torch import Tensor
 
 from . import _lib
@@ -79,20 +80,33 @@ def rope_(x: Tensor, seq_len: int, n_heads_rot: int, head_dim: int, table: Tenso
           "ssi_rope_inplace")
 
 
-def attn_fwd(qkv: Tensor, out: Tensor, lse: Tensor, batch: int, seq: int, n_heads: int, n_kv: int, head_dim: int) -> None:
+def _doc_ptrs(doc_start: Optional[Tensor], doc_end: Optional[Tensor], rows: int):
+    if doc_start is None and doc_end is None:
+        return None, None
+    assert doc_start is not None and doc_end is not None, "doc_start and doc_end go together"
+    for t in (doc_start, doc_end):
+        assert t.dtype == torch.int32 and t.is_contiguous() and t.numel() == rows
+    return ptr(doc_start), ptr(doc_end)
+
+
+def attn_fwd(qkv: Tensor, out: Tensor, lse: Tensor, batch: int, seq: int, n_heads: int, n_kv: int, head_dim: int,
+             doc_start: Optional[Tensor] = None, doc_end: Optional[Tensor] = None) -> None:
+    """Causal GQA attention; with doc_start / doc_end (int32 [batch*seq]) block-causal over the documents packed in a row."""
     assert qkv.dim() == 2 and qkv.stride(1) == 1 and out.is_contiguous() and lse.dtype == torch.float32
     assert qkv.shape[0] == batch * seq and out.numel() == batch * seq * n_heads * head_dim
     assert lse.numel() >= batch * n_heads * seq
-    check(_lib.load().ssi_attn_fwd(ptr(qkv), qkv.stride(0), ptr(out), ptr(lse), batch, seq, n_heads, n_kv, head_dim,
-                                   dtype_code(qkv.dtype), stream_ptr()), "ssi_attn_fwd")
+    ds, de = _doc_ptrs(doc_start, doc_end, batch * seq)
+    check(_lib.load().ssi_attn_varlen_fwd(ptr(qkv), qkv.stride(0), ptr(out), ptr(lse), ds, de, batch, seq, n_heads, n_kv, head_dim,
+                                          dtype_code(qkv.dtype), stream_ptr()), "ssi_attn_varlen_fwd")
 
 
 def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, dqkv: Tensor, delta: Tensor, batch: int, seq: int,
-             n_heads: int, n_kv: int, head_dim: int) -> None:
+             n_heads: int, n_kv: int, head_dim: int, doc_start: Optional[Tensor] = None, doc_end: Optional[Tensor] = None) -> None:
     assert qkv.stride(1) == 1 and dqkv.stride() == qkv.stride() and out.is_contiguous() and dout.is_contiguous()
     assert delta.dtype == torch.float32 and delta.numel() >= batch * n_heads * seq
-    check(_lib.load().ssi_attn_bwd(ptr(qkv), qkv.stride(0), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), batch,
-                                   seq, n_heads, n_kv, head_dim, dtype_code(qkv.dtype), stream_ptr()), "ssi_attn_bwd")
+    ds, de = _doc_ptrs(doc_start, doc_end, batch * seq)
+    check(_lib.load().ssi_attn_varlen_bwd(ptr(qkv), qkv.stride(0), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), ds, de, batch,
+                                          seq, n_heads, n_kv, head_dim, dtype_code(qkv.dtype), stream_ptr()), "ssi_attn_varlen_bwd")
 
 
 def swiglu_fwd(gu: Tensor, act: Tensor) -> None:

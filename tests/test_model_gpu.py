@@ -316,6 +316,57 @@ def test_hf_format_checkpoint_loads_into_the_hip_model_and_matches_hf_llama(tmp_
     assert written.keys() == sd_hf.keys() and all(torch.equal(written[k], sd_hf[k]) for k in sd_hf)
 
 
+@pytest.mark.parametrize("dtype_name", ["fp32", "bf16"])
+def test_packed_batch_matches_oracle_with_block_causal_mask(dtype_name):
+    """a packed batch (PackedDataset -> padded_collate_packed: tokens, labels, input_pos) through
+    ``compute_loss`` on the HIP model (block-causal attention + per-document RoPE positions derived from input_pos) against the
+    oracle fed torchtune's dense block-causal mask and the same input_pos: loss and every gradient.  fp32 = generic kernels,
+    bf16 = MFMA-shaped model (MFMA attention with the document masks, S padded to the MFMA tile)."""
+    from oracle import hf_crosscheck as hx
+    from oracle.llama_oracle import OracleCEWithChunkedOutputLoss
+    from oracle.llama_oracle import compute_loss as oracle_loss
+    from ssi.data import PackedDataset, packed_block_causal_mask, padded_collate_packed
+    from ssi.loss import CEWithChunkedOutputLoss, compute_loss
+    from ssi.model import HipLlamaDecoder
+    bf16 = dtype_name == "bf16"
+    params = (dict(vocab_size=700, num_layers=2, num_heads=4, num_kv_heads=2, embed_dim=256, max_seq_len=512, intermediate_dim=512) if bf16
+              else dict(vocab_size=515, num_layers=2, num_heads=8, num_kv_heads=2, embed_dim=128, max_seq_len=256, intermediate_dim=256))
+    S = 320 if bf16 else 100   # bf16: padded to 384 inside fused_loss
+    g = torch.Generator().manual_seed(51)
+    lengths = [57, 130, 9, 77, 160, 33, 101, 64, 12] if bf16 else [31, 7, 44, 13, 50, 26]
+    samples = []
+    for n in lengths:
+        toks = torch.randint(0, params["vocab_size"], (n,), generator=g).tolist()
+        labs = [(-100 if i < 3 else t) for i, t in enumerate(toks)]   # a masked prompt span at the head of every document
+        samples.append({"tokens": toks, "labels": labs})
+    packs = PackedDataset(samples, max_seq_len=S, padding_idx=0)
+    batch = padded_collate_packed([packs[0], packs[1]])
+    sd = hx.seeded_state_dict(params, 52)
+    ref_model = hx.oracle_model(params, sd)
+    ref_batch = {"tokens": batch["tokens"], "labels": batch["labels"], "input_pos": batch["input_pos"],
+                 "mask": packed_block_causal_mask(batch["seq_lens"])}
+    ref = oracle_loss(ref_batch, ref_model, OracleCEWithChunkedOutputLoss())
+    ref.backward()
+    model = HipLlamaDecoder(**params, dtype=torch.bfloat16 if bf16 else torch.float32, device=DEV)
+    model.load_state_dict(sd)
+    dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    loss = compute_loss(dbatch, model, CEWithChunkedOutputLoss())
+    loss.backward()
+    tol_l, tol_g = (1e-2, 6e-2) if bf16 else (1e-5, 5e-3)
+    assert abs(loss.item() - ref.item()) <= tol_l * abs(ref.item())
+    for (k, p), (_, p2) in zip(model.named_parameters(), ref_model.named_parameters()):
+        rel = float((p.grad.float().cpu() - p2.grad).norm() / p2.grad.norm())
+        assert rel <= tol_g, f"{k}: relative gradient error {rel}"
+    # the same rows WITHOUT input_pos are plain causal rows: a different loss (documents then see each other)
+    plain = compute_loss({"tokens": dbatch["tokens"], "labels": dbatch["labels"]}, model, CEWithChunkedOutputLoss())
+    assert abs(plain.item() - loss.item()) > 1e-4 * abs(loss.item())
+    # eval mode and the unfused route (model(tokens, input_pos=...) -> chunks -> CE) agree with the fused training loss
+    model.eval()
+    with torch.no_grad():
+        l_eval = compute_loss(dbatch, model, CEWithChunkedOutputLoss())
+    assert abs(l_eval.item() - loss.item()) <= 1e-6 * abs(loss.item()) + (1e-3 if bf16 else 0)
+
+
 def test_full_size_step_properties():
     """BASELINE config A at full size (Llama-3.2-1B + 5000 DSUs, B=8, S=2048, bf16): size-independent properties.
     (1) random-init loss ~ ln V; (2) bitwise reproducibility of loss and gradients; (3) gradient accumulation is additive;

@@ -1,0 +1,81 @@
+"""Packed batches, host side, CPU only: PackedDataset / padded_collate_packed semantics (restated from
+torchtune 0.5.0, which the reference stubs at ssi/data/__init__.py:66-73,202-205), the document ranges the attention kernels
+take, and the oracle's packed forward pinned against HF-Llama (position_ids + 4-D block-causal mask)."""
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from ssi.data import PackedDataset, packed_block_causal_mask, padded_collate_packed, synthetic_packed_batch  # noqa: E402
+
+
+def _samples(lengths):
+    out, base = [], 1
+    for n in lengths:
+        toks = list(range(base, base + n))
+        out.append({"tokens": toks, "labels": [t + 1000 for t in toks]})
+        base += n
+    return out
+
+
+def test_greedy_packing_padding_positions_and_seq_lens():
+    packs = PackedDataset(_samples([5, 4, 6, 3, 10]), max_seq_len=10, padding_idx=99)
+    assert len(packs) == 3
+    p0, p1, p2 = (packs[i] for i in range(3))
+    assert p0["tokens"].tolist() == list(range(1, 10)) + [99]                        # 5 + 4, one pad: the 6-sample opens pack 1
+    assert p0["labels"].tolist() == [t + 1000 for t in range(1, 10)] + [-100]
+    assert p0["input_pos"].tolist() == [0, 1, 2, 3, 4, 0, 1, 2, 3, 4]                # pad continues the last document's range
+    assert p0["seq_lens"].tolist() == [5, 4, 1]                                     # padding counted as one more entry
+    assert p1["seq_lens"].tolist() == [6, 3, 1] and p1["input_pos"].tolist() == [0, 1, 2, 3, 4, 5, 0, 1, 2, 3]
+    assert p2["seq_lens"].tolist() == [10] and p2["input_pos"].tolist() == list(range(10))   # exact fit: no padding entry
+    with pytest.raises(ValueError, match="too long"):
+        PackedDataset(_samples([11]), max_seq_len=10)
+    split = PackedDataset(_samples([7, 7]), max_seq_len=10, split_across_pack=True)
+    assert [p["seq_lens"].tolist() for p in split] == [[7, 3], [4, 6]]
+    assert split[1]["input_pos"].tolist()[:4] == [0, 1, 2, 3]                        # the cut remainder restarts at 0 (torchtune)
+    batch = padded_collate_packed([p0, p1])
+    assert batch["tokens"].shape == (2, 10) and batch["input_pos"].shape == (2, 10) and "mask" not in batch
+    assert len(PackedDataset(_samples([5, 4, 6, 3, 10]), max_seq_len=10, max_packs=2)) == 2
+
+
+def test_document_ranges_equal_the_block_causal_mask_for_real_tokens():
+    from ssi.model import HipLlamaDecoder
+    batch = synthetic_packed_batch(3, 512, doc_len=150, seed=7)
+    pos, ds, de = HipLlamaDecoder._document_ranges(batch["input_pos"])
+    B, S = batch["tokens"].shape
+    ds, de = ds.view(B, S).long(), de.view(B, S).long()
+    dense = packed_block_causal_mask(batch["seq_lens"])
+    idx = torch.arange(S)
+    mine = (idx[None, None, :] >= ds[:, :, None]) & (idx[None, None, :] <= idx[None, :, None])     # [b, q, k]
+    for b in range(B):
+        lens = batch["seq_lens"][b]
+        padded = bool(batch["labels"][b, -1] == -100) and len(lens) > 1 and int(batch["input_pos"][b, -int(lens[-1])]) != 0
+        n = int(lens[:-1].sum()) if padded else S   # real tokens: the padding tail joins the last document here, is a block there
+        assert torch.equal(mine[b, :n, :], dense[b, :n, :])          # every real query sees exactly torchtune's keys
+        assert not mine[b, :n, n:].any()                             # and never a padding key
+    vis = (idx[None, :, None] >= idx[None, None, :]) & (idx[None, :, None] < de[:, None, :])       # key k seen by k <= q < doc_end[k]
+    assert torch.equal(vis, mine)
+    assert torch.equal(pos.view(B, S).long(), batch["input_pos"])
+
+
+def test_oracle_packed_forward_matches_hf_llama():
+    """position_ids + block-causal mask in HF-Llama == input_pos + mask in the oracle (torchtune semantics)."""
+    from oracle import hf_crosscheck as hx
+    params = dict(vocab_size=515, num_layers=2, num_heads=8, num_kv_heads=2, embed_dim=128, max_seq_len=64, intermediate_dim=256)
+    sd = hx.seeded_state_dict(params, 41)
+    packs = PackedDataset(_samples([11, 7, 20, 9, 13]), max_seq_len=32, padding_idx=0)
+    batch = padded_collate_packed([packs[0], packs[1]])
+    tokens = batch["tokens"] % 515
+    mask = packed_block_causal_mask(batch["seq_lens"])
+    oracle = hx.oracle_model(params, sd, chunks=0)
+    hf = hx.build_hf(params, sd)
+    with torch.no_grad():
+        got = oracle(tokens, mask=mask, input_pos=batch["input_pos"]).float()
+        add = torch.zeros(mask.shape, dtype=torch.float32).masked_fill(~mask, torch.finfo(torch.float32).min)[:, None]
+        ref = hf(input_ids=tokens, position_ids=batch["input_pos"], attention_mask=add).logits
+    real = batch["labels"] != -100
+    assert float((got - ref)[real].abs().max()) <= 2e-5 * float(ref.abs().max())
