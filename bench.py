@@ -203,6 +203,9 @@ def main() -> int:
     ap.add_argument("--n-dsus", type=int, default=5000)
     ap.add_argument("--layers", type=int, default=16, help="debug only; the headline number needs 16")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--packed", action="store_true",
+                    help="secondary workload (BASELINE config E at one GPU): rows packed with ~440-1100-token documents, block-causal "
+                         "attention; use with --seq 8192 --batch 2.  Not the headline line.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timing", action="store_true")
     args = ap.parse_args()
@@ -217,7 +220,7 @@ def main() -> int:
     torch.cuda.set_device(device)
 
     import copy
-    from ssi.data import synthetic_batch
+    from ssi.data import synthetic_batch, synthetic_packed_batch
     from ssi.distributed import GradSync, all_reduce_scalars, init_distributed
     from ssi.llama_configs import configllama3_2_1b
     from ssi.loss import CEWithChunkedOutputLoss, compute_loss
@@ -251,8 +254,12 @@ def main() -> int:
     pad_id = lcfg._base_vocab_size_txt + lcfg.n_dsus + 2 + 4
 
     n_total = args.warmup + args.steps
-    batches = [{k: v.to(device) for k, v in synthetic_batch(args.batch, args.seq, args.n_dsus, rank=rank, index=i % 4).items()}
-               for i in range(min(n_total, 4))]
+    if args.packed:
+        batches = [{k: (v.to(device) if torch.is_tensor(v) else v)
+                    for k, v in synthetic_packed_batch(args.batch, args.seq, args.n_dsus, seed=42_831 + i, rank=rank).items()} for i in range(min(n_total, 4))]
+    else:
+        batches = [{k: v.to(device) for k, v in synthetic_batch(args.batch, args.seq, args.n_dsus, rank=rank, index=i % 4).items()}
+                   for i in range(min(n_total, 4))]
     timer = GemmTimer()
     if not args.no_gemm_timing and rank == 0:
         timer.install()
@@ -297,13 +304,21 @@ def main() -> int:
     tokens_per_step = args.batch * args.seq * world
     value = tokens_per_step * args.steps / elapsed
     f_tok = flops_per_token(lcfg.vocab_size, args.seq, layers=args.layers) if args.layers == 16 else None
+    if args.packed and f_tok:  # attention term over the documents instead of the whole row
+        nn, n1 = 0.0, 0.0
+        for bt in batches:
+            for lens in bt["seq_lens"]:
+                nn += float((lens.double() * (lens.double() + 1)).sum())
+                n1 += float(lens.sum())
+        f_tok = flops_per_token(lcfg.vocab_size, 0, layers=args.layers) - 3 * 2 * args.layers * 2048 + 3 * 2 * args.layers * 2048 * nn / n1
     if rank == 0:
         out = {
             "metric": "train_tokens_per_sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"Llama-3.2-1B +{args.n_dsus} DSUs (V={lcfg.vocab_size}), SFT step fwd+bwd+AdamW, seq_len={args.seq}, "
-                                   f"batch={args.batch}/GPU, grad_accum=1, {args.layers} layers, random-init weights, MLS-shaped synthetic DSU sequences",
+                                   f"batch={args.batch}/GPU, grad_accum=1, {args.layers} layers, random-init weights, MLS-shaped synthetic DSU sequences"
+                                   + (", rows packed with 440-1100-token documents (block-causal attention)" if args.packed else ""),
                        "global_batch": args.batch * world, "seq_len": args.seq, "parallelism": f"dp{world}", "last_loss": loss},
         }
         if f_tok:
