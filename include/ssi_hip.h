@@ -35,6 +35,12 @@ enum { SSI_OK = 0, SSI_ERR_ARG = 1, SSI_ERR_UNSUPPORTED = 2, SSI_ERR_WORKSPACE =
  *   TN: A[K,M]  B[K,N]   C = A^T * B   weight gradient dW = dy^T x                                                  */
 enum { SSI_GEMM_NT = 0, SSI_GEMM_NN = 1, SSI_GEMM_TN = 2 };
 /* which implementation ssi_gemm may use: AUTO picks the MFMA kernel when shape/dtype allow, else the generic one */
+/* Order in which the workgroups of the persistent MFMA GEMM take output tiles.  STATIC (default): tile b, b+G, ... — optimal
+ * when the GEMM has the GPU to itself.  DYNAMIC: tiles are drawn from per-XCD counters, so a workgroup that starts late because
+ * another kernel holds its CU (RCCL during the data-parallel gradient exchange) costs its share of tiles instead of a round. */
+enum { SSI_TILES_STATIC = 0, SSI_TILES_DYNAMIC = 1 };
+int ssi_set_gemm_tile_order(int mode);
+
 enum { SSI_IMPL_AUTO = 0, SSI_IMPL_GENERIC = 1, SSI_IMPL_MFMA = 2,
        SSI_IMPL_MFMA_WG8 = 3 /* debug / A-B runs: MFMA paths, but the NT GEMM restricted to the 8-wave LDS-DMA kernel */ };
 

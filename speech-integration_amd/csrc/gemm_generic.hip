@@ -21,6 +21,13 @@ extern "C" int ssi_set_impl(int impl) {
 }
 int ssi_get_impl() { return g_impl; }
 
+void ssi_gemm_mfma_set_dynamic_tiles(int on);
+extern "C" int ssi_set_gemm_tile_order(int mode) {
+    if (mode != SSI_TILES_STATIC && mode != SSI_TILES_DYNAMIC) { ssi_set_error("ssi_set_gemm_tile_order: mode %d", mode); return SSI_ERR_ARG; }
+    ssi_gemm_mfma_set_dynamic_tiles(mode == SSI_TILES_DYNAMIC);
+    return SSI_OK;
+}
+
 // element (m,k) of op(A) at A[m*sam + k*sak]; element (k,n) of op(B) at B[k*sbk + n*sbn]
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A,

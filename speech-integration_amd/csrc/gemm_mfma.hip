@@ -18,6 +18,7 @@
 //       the residual / previous C in the same pass (same rounding points as F.linear followed by `+`).
 // Workgroup -> tile map: XCD-aware (consecutive tiles of a group share A rows / B columns inside one XCD's L2).
 #include "common.cuh"
+#include <atomic>
 #include <type_traits>
 
 int ssi_get_impl();
@@ -119,6 +120,20 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
     tm = group * GM + in_group % gm;
     tn = in_group / gm;
 }
+
+// grouped order of the tile sequence: GM m-tiles x all n-tiles per group (second half of tile_coords)
+__device__ __forceinline__ void tile_from_t(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
+    constexpr int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int group = t / per_group, in_group = t % per_group;
+    const int gm = (tiles_m - group * GM) < GM ? (tiles_m - group * GM) : GM;
+    tm = group * GM + in_group % gm;
+    tn = in_group / gm;
+}
+
+// Tile scheduler state of the persistent kernel: per launch slot, 8 per-XCD "next tile of my span" counters + a count of
+// finished workgroups (the last one to finish clears the slot for its next use).  Static device memory, no allocation.
+__device__ int g_nt4_sched[16][16];
 
 // SPLITK: blockIdx.y selects a contiguous range of K-tiles; the fp32 partial tile goes to slab[blockIdx.y] (an [M, N] fp32
 // matrix in the workspace) and splitk_reduce_kernel applies alpha / accumulate / residual and the bf16 rounding.
@@ -453,7 +468,8 @@ int launch(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, cons
 //   * 256 threads = 4 waves as 2 x 2, 128 x 128 outputs per wave: all 256 AGPRs hold accumulators, LDS fragment traffic is
 //     2/3 of the 8-wave kernel's.  The MFMAs are inline asm with the accumulator tied in place: with the whole AGPR file in
 //     use the builtin form makes the allocator rotate accumulators through copies (hundreds of v_accvgpr moves per K-tile).
-//   * gridDim.x (= CUs) workgroups walk the output tiles b, b + G, ...  The global -> VGPR -> LDS operand stream runs three
+//   * gridDim.x (= CUs) workgroups draw output tiles from a scheduler (per-XCD spans, see below) until none is left; the
+//     order in which tiles are handed out is the XCD-aware grouped order.  The global -> VGPR -> LDS operand stream runs three
 //     K-steps ahead of the MFMAs through two alternating register sets (every load has two full K-steps to land) and does
 //     not stop at tile boundaries: a tile's first operands arrive while the previous tile is still being multiplied.
 //   * One K-step = 8 blocks of 16 MFMAs.  Four fragment slots (4 x 16 rows x 32 k each) rotate so that each block fetches
@@ -469,6 +485,12 @@ int launch(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, cons
 #define NT4_ST_AUX 0
 #endif
 constexpr int NT4_THREADS = 256;
+constexpr int NT4_LDS_BYTES = PIPE_BYTES + 16;  // operand pipeline + the scheduler's broadcast word
+std::atomic<int> g_nt4_dynamic{0};
+inline unsigned nt4_next_slot() {
+    static std::atomic<unsigned> n{0};
+    return n.fetch_add(1, std::memory_order_relaxed);
+}
 constexpr int NT4_WM = 128, NT4_WN = 128;
 constexpr unsigned BUF_RSRC_DW3 = 0x00020000u;  // raw buffer, 32-bit data format (gfx9 family)
 
@@ -484,13 +506,59 @@ template <bool A_COL, bool B_COL, int EPI, int PREV>
 __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, int tiles_n, int64_t K, const bf16_t* __restrict__ A,
                                                                   int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                                   bf16_t* __restrict__ C, int64_t ldc, const bf16_t* __restrict__ R,
-                                                                  float alpha, const float* __restrict__ alpha_dev, EpiArgs ea) {
+                                                                  float alpha, const float* __restrict__ alpha_dev, EpiArgs ea, int slot) {  // slot < 0: static tile order
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int ntiles = tiles_m * tiles_n, G = (int)gridDim.x;
-    const int nk = (int)(K / BK);  // even
+    const int nk = (int)(K / BK);  // even, >= 4
+
+    // ---- tile scheduler: workgroups draw tiles from the contiguous span of their XCD (operand panels stay in that XCD's L2) and,
+    // once it is empty, from the other spans.  Dynamic rather than "tile b, b+G, ...": a workgroup that starts late, or not at all,
+    // because another kernel (RCCL during the gradient exchange) holds its CU, then costs its share of tiles, not a whole round.
+    // The first tile of a workgroup is fixed (index b/8 of its XCD's span), later ones come from the span's atomic counter; the
+    // request for the tile after next is issued at the start of a tile and read at its end, so its round trip is never waited for.
+    int* sched = g_nt4_sched[slot < 0 ? 0 : slot];
+    volatile int* lds_next = reinterpret_cast<volatile int*>(smem + PIPE_BYTES);
+    const int xcd = (int)blockIdx.x & 7, span_q = ntiles >> 3, span_r = ntiles & 7;
+    auto span_len = [&](int x) { return span_q + (x < span_r ? 1 : 0); };
+    auto span_lo = [&](int x) { return x < span_r ? x * (span_q + 1) : span_r * (span_q + 1) + (x - span_r) * span_q; };
+    auto span_fixed = [&](int x) { const int n = (G - x + 7) >> 3; return n < span_len(x) ? n : span_len(x); };  // tiles given out statically
+    // slot < 0 = static order (tile index += G/8 within the span): optimal when every workgroup has its CU from the start, since
+    // equal tiles then need no balancing and a greedy scheduler can only hurt (a workgroup that is a little early takes a third
+    // tile where everybody should do two: measured -3..-12 % on the 2-3-round shapes).  The trainer switches to the dynamic
+    // order when the gradient exchange shares the GPU with the backward GEMMs (world size > 1).
+    const bool dynamic = slot >= 0;
+    int my_idx = (int)blockIdx.x >> 3;  // static order: position inside the span
+    int pending = 0;
+    auto request_tile = [&]() {
+        if (dynamic && tid == 0) pending = atomicAdd(&sched[xcd], 1);
+    };
+    auto receive_tile = [&]() -> int {
+        if (!dynamic) {
+            my_idx += G >> 3;
+            return ((G & 7) == 0 && my_idx < span_len(xcd)) ? span_lo(xcd) + my_idx : -1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everybody has read the previous answer
+        if (tid == 0) {
+            int t = -1;
+            const int i = pending + span_fixed(xcd);
+            if (i < span_len(xcd)) t = span_lo(xcd) + i;
+            for (int k = 1; k < 8 && t < 0; ++k) {  // own span empty: take from the others (only at the very end of a launch)
+                const int x = (xcd + k) & 7;
+                if (span_fixed(x) >= span_len(x)) continue;
+                const int j = atomicAdd(&sched[x], 1) + span_fixed(x);
+                if (j < span_len(x)) t = span_lo(x) + j;
+            }
+            *lds_next = t;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        return __builtin_amdgcn_readfirstlane(*lds_next);
+    };
+    int cur = ((int)blockIdx.x >> 3) < span_len(xcd) ? span_lo(xcd) + ((int)blockIdx.x >> 3) : -1;
+    int nxt = -1;
+    if (cur >= 0) request_tile();  // answered while the first operands are on their way
 
     f32x4 acc[8][8];  // [j (n-tile)][i (m-tile)], defined by the zero-C MFMAs of each tile's first K-step
     // LDS: [A buf 0 | A buf 1 | B buf 0 | B buf 1]; with the buffer index a compile-time constant every fragment address is one
@@ -499,21 +567,20 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     auto tileB = [&](int buf) { return smem + 2 * TILE_BYTES + buf * TILE_BYTES; };
 
     // ---- load side: (lv, lkt) = output tile and K-tile of the next fetch ------------------------------------------------
-    int lv = (int)blockIdx.x, lkt = 0;
+    int lkt = 0;
     const bf16_t* baseA = A;
     const bf16_t* baseB = B;
-    auto set_load_tile = [&](int v) {
+    auto set_load_tile = [&](int t) {
         int tm, tn;
-        tile_coords(v, tiles_m, tiles_n, tm, tn);
+        tile_from_t(t, tiles_m, tiles_n, tm, tn);
         baseA = A_COL ? A + (int64_t)tm * BM : A + (int64_t)tm * BM * lda;
         // SwiGLU forward: the 256 tile columns are [gate 0..63 | up 0..63 | gate 64..127 | up 64..127] of 128 W13 column pairs
         baseB = B_COL ? B + (int64_t)tn * BN : B + (int64_t)tn * (EPI == EPI_SWIGLU_FWD ? BN / 2 : BN) * ldb;
     };
     auto advance = [&]() {
-        if (++lkt == nk) {
+        if (++lkt == nk) {  // the fetches run at most 3 K-steps ahead of the MFMAs: this is always the switch to tile `nxt`
             lkt = 0;
-            lv += G;
-            if (lv < ntiles) set_load_tile(lv);  // past the last tile: keep re-fetching valid memory, never consumed
+            if (nxt >= 0) set_load_tile(nxt);  // after the last tile: keep re-fetching valid memory, never consumed
         }
     };
     // staging, ROW tiles: piece p = rows p*32 + (tid >> 3), 16-B chunk (tid & 7), swizzled on the LDS side.  COL tiles: piece p =
@@ -626,7 +693,8 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
         for (int p = 0; p < 8; ++p) gloadB(xb[p], p);
         advance();
     };
-    set_load_tile(lv);
+    set_load_tile(cur >= 0 ? cur : 0);
+    if (nk == 0) return;  // (never: keeps the scheduler state below out of a degenerate launch)
     fetch_step(ra0, rb0);
 #pragma unroll
     for (int p = 0; p < 8; ++p) lwriteA(tileA(0), p, ra0[p]);
@@ -637,14 +705,18 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int q = 0; q < 4; ++q) { rdA1(S0[q], tileA(0), 0, 0, q); rdB1(S1[q], tileB(0), 0, 0, q); }
+    if (cur >= 0) nxt = receive_tile();
 
     const float al = alpha * (alpha_dev ? *alpha_dev : 1.f);
     const int g = lane >> 4;
-    for (int v = (int)blockIdx.x; v < ntiles; v += G) {
+    while (cur >= 0) {
         int tm, tn;
-        tile_coords(v, tiles_m, tiles_n, tm, tn);
+        tile_from_t(cur, tiles_m, tiles_n, tm, tn);
         using B0_ = std::integral_constant<int, 0>;
         using B1_ = std::integral_constant<int, 1>;
+        // the tile after next is requested now and read after the epilogue: the answer is the oldest vector-memory operation in
+        // flight, so the counted waits of the K-steps below retire it (asking later would mean waiting for the epilogue's stores)
+        if (nxt >= 0) request_tile();
         body(B0_{}, ra1, rb1, std::true_type{});
         body(B1_{}, ra0, rb0, F_{});
         for (int kt = 2; kt < nk; kt += 2) {
@@ -806,10 +878,18 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
         };
         if (al == 1.f) epilogue(std::false_type{});
         else epilogue(std::true_type{});
+        cur = nxt;
+        if (cur >= 0) nxt = receive_tile();
         // the first fragments of the next tile (its K-step 0 sits in LDS buffer 0) are read again here rather than kept live
         // across the epilogue
 #pragma unroll
         for (int q = 0; q < 4; ++q) { rdA1(S0[q], tileA(0), 0, 0, q); rdB1(S1[q], tileB(0), 0, 0, q); }
+    }
+    // the last workgroup to get here clears the scheduler slot for the launch that uses it next
+    if (dynamic && tid == 0 && atomicAdd(&sched[8], 1) == G - 1) {  // plain stores: nobody reads the slot before this kernel has ended
+        volatile int* vs = sched;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) vs[i] = 0;
     }
 }
 
@@ -820,8 +900,8 @@ int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, 
     static bool attr_set = false;  // per instantiation
     static int num_cu = 256;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_BYTES);
-        if (e != hipSuccess) { ssi_set_error("gemm_nt4: cannot reserve %d B of LDS: %s", PIPE_BYTES, hipGetErrorString(e)); return SSI_ERR_HIP + (int)e; }
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NT4_LDS_BYTES);
+        if (e != hipSuccess) { ssi_set_error("gemm_nt4: cannot reserve %d B of LDS: %s", NT4_LDS_BYTES, hipGetErrorString(e)); return SSI_ERR_HIP + (int)e; }
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -830,18 +910,20 @@ int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, 
     }
     const int ntiles = tiles_m * tiles_n;
     int grid = ntiles < num_cu ? ntiles : num_cu;
-    if (grid >= 8) grid &= ~7;  // whole XCD rounds keep the tile -> XCD map of tile_coords intact
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT4_THREADS), PIPE_BYTES, st, tiles_m, tiles_n, K, (const bf16_t*)A, lda,
-                       (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (const bf16_t*)R, alpha, alpha_dev, ea);
+    const int slot = g_nt4_dynamic.load(std::memory_order_relaxed) ? (int)(nt4_next_slot() & 15) : -1;  // consecutive launches: different slots
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT4_THREADS), NT4_LDS_BYTES, st, tiles_m, tiles_n, K, (const bf16_t*)A, lda,
+                       (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (const bf16_t*)R, alpha, alpha_dev, ea, slot);
     SSI_LAUNCH_CHECK();
     return SSI_OK;
 }
 
-bool nt4_ok(int64_t K) { return K % (2 * BK) == 0 && ssi_get_impl() != SSI_IMPL_MFMA_WG8; }
+bool nt4_ok(int64_t K) { return K % (2 * BK) == 0 && K >= 4 * BK && ssi_get_impl() != SSI_IMPL_MFMA_WG8; }
 // buffer-load offsets are 32-bit: a tile's rows (k-contiguous) or one K-step's k-rows (k-strided) must stay within 2 GiB
 bool nt4_ld_ok(int64_t lda, int64_t ldb) { return 256 * lda * 2 < (1LL << 31) && 256 * ldb * 2 < (1LL << 31); }
 
 }  // namespace
+
+void ssi_gemm_mfma_set_dynamic_tiles(int on) { g_nt4_dynamic.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 bool ssi_gemm_mfma_supported(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                              int64_t ldb, const void* C, int64_t ldc, const void* R) {

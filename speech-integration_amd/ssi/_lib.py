@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("SSI_HIP_LIB") or os.path.join(os.path.dirname(_HERE),
 SSI_F32, SSI_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_MFMA_WG8 = 0, 1, 2, 3
+TILES_STATIC, TILES_DYNAMIC = 0, 1
 ABI_VERSION = 1
 
 # name -> (restype, argtypes); mirrors include/ssi_hip.h line by line
@@ -36,6 +37,7 @@ PROTOTYPES = {
     "ssi_rope_inplace": (c_int, [_P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, _P, c_int, c_int, _P]),
     "ssi_attn_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_int, _P]),
     "ssi_attn_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_int, _P]),
+    "ssi_set_gemm_tile_order": (c_int, [c_int]),
     "ssi_attn_varlen_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_int, _P]),
     "ssi_attn_varlen_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_int, _P]),
     "ssi_swiglu_fwd": (c_int, [_P, _P, c_int64, c_int64, c_int, _P]),

@@ -55,6 +55,11 @@ class GradSync:
         self._done: set[str] = set()
         self._comm_stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         self.bytes_reduced = 0
+        if flat_grad.is_cuda and self.enabled:
+            # RCCL's kernels hold CUs for the length of a reduction while the backward GEMMs run: a persistent GEMM with a fixed
+            # tile-to-workgroup map would wait a whole round for the workgroups that could not start (include/ssi_hip.h)
+            from . import ops
+            ops.set_gemm_tile_order(dynamic=True)
 
     @property
     def enabled(self) -> bool:

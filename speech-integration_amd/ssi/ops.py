@@ -89,6 +89,11 @@ def _doc_ptrs(doc_start: Optional[Tensor], doc_end: Optional[Tensor], rows: int)
     return ptr(doc_start), ptr(doc_end)
 
 
+def set_gemm_tile_order(dynamic: bool) -> None:
+    """Dynamic tile order for the persistent GEMMs (use when other kernels share the GPU, e.g. RCCL during backward)."""
+    check(_lib.load().ssi_set_gemm_tile_order(_lib.TILES_DYNAMIC if dynamic else _lib.TILES_STATIC), "ssi_set_gemm_tile_order")
+
+
 def attn_fwd(qkv: Tensor, out: Tensor, lse: Tensor, batch: int, seq: int, n_heads: int, n_kv: int, head_dim: int,
              doc_start: Optional[Tensor] = None, doc_end: Optional[Tensor] = None) -> None:
     """Causal GQA attention; with doc_start / doc_end (int32 [batch*seq]) block-causal over the documents packed in a row."""

@@ -328,6 +328,48 @@ def test_gemm_persistent_kernel_walks_many_tiles(ops, layout, mode):
     assert torch.equal(cs[0], cs[1])
 
 
+def test_gemm_persistent_kernels_share_the_gpu_with_the_dynamic_tile_order(ops):
+    """Two persistent GEMMs launched back to back on two streams: each asks for every CU, so half of the workgroups of either
+    start late or only when the other kernel ends (what RCCL's kernels do to the backward GEMMs during the gradient exchange).
+    The dynamic tile scheduler must hand every tile out exactly once whatever the interleaving: results equal the serial ones."""
+    ops.set_gemm_tile_order(dynamic=True)
+    a1, b1 = _gemm_operands(0, 4096, 4096, 1024, torch.bfloat16, 81)
+    a2, b2 = _gemm_operands(2, 2048, 8192, 2048, torch.bfloat16, 82)
+    a1, b1, a2, b2 = a1.to(DEV), b1.to(DEV), a2.to(DEV), b2.to(DEV)
+    ref1 = torch.empty(4096, 4096, dtype=torch.bfloat16, device=DEV)
+    ref2 = torch.empty(2048, 8192, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(0, a1, b1, ref1)
+    ops.gemm(2, a2, b2, ref2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(5):
+        c1 = torch.full_like(ref1, float("nan"))
+        c2 = torch.full_like(ref2, float("nan"))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            for _ in range(3):
+                ops.gemm(0, a1, b1, c1)
+        with torch.cuda.stream(s2):
+            for _ in range(3):
+                ops.gemm(2, a2, b2, c2)
+        torch.cuda.synchronize()
+        assert torch.equal(c1, ref1) and torch.equal(c2, ref2)
+    ops.set_gemm_tile_order(dynamic=False)
+    # the dynamic order on every layout / epilogue class, many tiles per workgroup, alone on the GPU: same bits as the static order
+    for layout in (0, 1, 2):
+        a, b = _gemm_operands(layout, 4096, 8192, 512, torch.bfloat16, 83 + layout)
+        a, b = a.to(DEV), b.to(DEV)
+        r = rnd(4096, 8192, dtype=torch.bfloat16, seed=86).to(DEV)
+        outs = []
+        for dyn in (False, True):
+            ops.set_gemm_tile_order(dynamic=dyn)
+            c = torch.full((4096, 8192), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(layout, a, b, c, residual=r)
+            outs.append(c)
+        ops.set_gemm_tile_order(dynamic=False)
+        assert torch.equal(outs[0], outs[1])
+
+
 def test_gemm_weight_gradient_form_beyond_2gib_of_k_offset(ops):
     """TN form on a column window of a [K, ld] operand whose K extent spans more than 2 GiB (the LM-head weight gradient is
     such a case): the K offset must not ride in a 32-bit buffer offset."""
