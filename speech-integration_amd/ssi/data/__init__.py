@@ -6,8 +6,9 @@ right-padded with ``pad_id`` / ``-100`` (``/root/reference/ssi/data/__init__.py:
 that contract; ``SyntheticDSUDataset`` produces sequences with the vocabulary layout and span statistics of MLS HuBERT
 DSU data for benchmarks and tests."""
 
+from .prefetch import DevicePrefetcher
 from .packed import PackedDataset, pack_dataset, packed_block_causal_mask, padded_collate_packed
 from .synthetic import SyntheticDSUDataset, padded_collate_sft, setup_synthetic_data, synthetic_batch, synthetic_packed_batch
 
-__all__ = ["SyntheticDSUDataset", "padded_collate_sft", "setup_synthetic_data", "synthetic_batch", "synthetic_packed_batch", "PackedDataset", "pack_dataset",
+__all__ = ["SyntheticDSUDataset", "padded_collate_sft", "setup_synthetic_data", "synthetic_batch", "synthetic_packed_batch", "DevicePrefetcher", "PackedDataset", "pack_dataset",
            "packed_block_causal_mask", "padded_collate_packed"]

@@ -294,11 +294,16 @@ class Trainer:
             self.sampler_train.set_epoch(epoch)
         if hasattr(self.data_train.dataset, "set_epoch"):
             self.data_train.dataset.set_epoch(epoch)
+        # batches are collated, pinned and copied to the device two ahead of the step by a background thread (ssi/data/prefetch.py)
+        source = self.data_train
+        if self.device.type == "cuda" and self.cfg.get("prefetch_batches", 2):
+            from .data.prefetch import DevicePrefetcher
+            source = DevicePrefetcher(self.data_train, self.device, depth=int(self.cfg.get("prefetch_batches", 2)))
         if batches_to_skip > 0:
             LOGGER.info(f"Resuming: skipping {batches_to_skip} batches in epoch {epoch}")
-            data_iter = itertools.islice(enumerate(self.data_train), batches_to_skip, self.geometry.usable_batches)
+            data_iter = itertools.islice(enumerate(source), batches_to_skip, self.geometry.usable_batches)
         else:
-            data_iter = itertools.islice(enumerate(self.data_train), self.geometry.usable_batches)
+            data_iter = itertools.islice(enumerate(source), self.geometry.usable_batches)
         ga = self.cfg.gradient_accumulation_steps
         for i, batch in data_iter:
             boundary = (i + 1) % ga == 0

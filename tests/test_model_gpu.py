@@ -367,6 +367,17 @@ def test_packed_batch_matches_oracle_with_block_causal_mask(dtype_name):
     assert abs(l_eval.item() - loss.item()) <= 1e-6 * abs(loss.item()) + (1e-3 if bf16 else 0)
 
 
+def test_device_prefetcher_delivers_device_batches_in_order():
+    from ssi.data import DevicePrefetcher, setup_synthetic_data
+    loader, _ = setup_synthetic_data(n_samples=24, seq_len=96, batch_size=4, n_dsus=100, shuffle=False, fixed_len=False)
+    ref = [b for b in loader]
+    got = [b for b in DevicePrefetcher(loader, DEV, depth=2)]
+    assert len(got) == len(ref) == 6
+    for a, b in zip(ref, got):
+        assert b["tokens"].is_cuda and b["labels"].is_cuda
+        assert torch.equal(b["tokens"].cpu(), a["tokens"]) and torch.equal(b["labels"].cpu(), a["labels"])
+
+
 def test_full_size_step_properties():
     """BASELINE config A at full size (Llama-3.2-1B + 5000 DSUs, B=8, S=2048, bf16): size-independent properties.
     (1) random-init loss ~ ln V; (2) bitwise reproducibility of loss and gradients; (3) gradient accumulation is additive;

@@ -79,3 +79,39 @@ def test_oracle_packed_forward_matches_hf_llama():
         ref = hf(input_ids=tokens, position_ids=batch["input_pos"], attention_mask=add).logits
     real = batch["labels"] != -100
     assert float((got - ref)[real].abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_device_prefetcher_order_passthrough_and_errors():
+    """ssi/data/prefetch.py on a CPU device: loader order kept, non-tensor values pass through, loader exceptions re-raise in the
+    consumer, early exit stops the worker, attributes of the wrapped loader stay reachable."""
+    from ssi.data import DevicePrefetcher
+
+    class Loader:
+        sampler = "S"
+
+        def __init__(self, n, fail_at=None):
+            self.n, self.fail_at, self.produced = n, fail_at, 0
+
+        def __len__(self):
+            return self.n
+
+        def __iter__(self):
+            for i in range(self.n):
+                if i == self.fail_at:
+                    raise RuntimeError("boom")
+                self.produced += 1
+                yield {"tokens": torch.full((2, 3), i), "ids": [i, i + 1]}
+
+    pf = DevicePrefetcher(Loader(7), "cpu", depth=2)
+    got = list(pf)
+    assert [int(b["tokens"][0, 0]) for b in got] == list(range(7)) and got[3]["ids"] == [3, 4]
+    assert len(pf) == 7 and pf.sampler == "S"
+    with pytest.raises(RuntimeError, match="boom"):
+        list(DevicePrefetcher(Loader(5, fail_at=2), "cpu"))
+    ld = Loader(1000)
+    for i, b in enumerate(DevicePrefetcher(ld, "cpu", depth=2)):
+        if i == 3:
+            break
+    assert ld.produced <= 3 + 1 + 2 + 1  # consumed + in hand + queue depth + one being produced
+    with pytest.raises(ValueError):
+        DevicePrefetcher(Loader(1), "cpu", depth=0)
