@@ -484,6 +484,9 @@ int launch(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, cons
 #ifndef NT4_ST_AUX
 #define NT4_ST_AUX 0
 #endif
+#ifndef NT4_ST_AUX_BIG  // outputs far larger than the 256 MiB Infinity Cache (gate/up/act of the fused SwiGLU forward, 0.8 GB)
+#define NT4_ST_AUX_BIG 2
+#endif
 constexpr int NT4_THREADS = 256;
 constexpr int NT4_LDS_BYTES = PIPE_BYTES + 16;  // operand pipeline + the scheduler's broadcast word
 std::atomic<int> g_nt4_dynamic{0};
@@ -821,9 +824,9 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
                     const u32x4& gq = h ? ghi : glo;
                     const u32x4& uq = h ? uhi : ulo;
                     const int so = (int)(((i * 16 + h * 8) * ldc) * 2), so2 = (int)(((i * 16 + h * 8) * ea.ld_out2) * 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(gq, rsGU, voff, so, NT4_ST_AUX);
-                    __builtin_amdgcn_raw_buffer_store_b128(uq, rsGU, voff, so + up_off, NT4_ST_AUX);
-                    __builtin_amdgcn_raw_buffer_store_b128(act_of(gq, uq), rsACT, voff2, so2, NT4_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(gq, rsGU, voff, so, NT4_ST_AUX_BIG);
+                    __builtin_amdgcn_raw_buffer_store_b128(uq, rsGU, voff, so + up_off, NT4_ST_AUX_BIG);
+                    __builtin_amdgcn_raw_buffer_store_b128(act_of(gq, uq), rsACT, voff2, so2, NT4_ST_AUX_BIG);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
