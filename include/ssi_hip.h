@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SSI_ABI_VERSION 1
+#define SSI_ABI_VERSION 2 /* 2: + ssi_attn_varlen_fwd/bwd, ssi_set_gemm_tile_order, NN form of ssi_gemm_swiglu_bwd */
 
 enum { SSI_F32 = 0, SSI_BF16 = 1 };
 enum { SSI_OK = 0, SSI_ERR_ARG = 1, SSI_ERR_UNSUPPORTED = 2, SSI_ERR_WORKSPACE = 3, SSI_ERR_HIP = 1000 /* + hipError_t */ };

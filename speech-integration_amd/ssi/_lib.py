@@ -20,7 +20,7 @@ SSI_F32, SSI_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_MFMA_WG8 = 0, 1, 2, 3
 TILES_STATIC, TILES_DYNAMIC = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # name -> (restype, argtypes); mirrors include/ssi_hip.h line by line
 _P = c_void_p
