@@ -505,17 +505,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 //      back with ds_read_b64_tr_b16, as in the 8-wave kernel).  NT = (false, false), NN = (false, true: data gradients against
 //      the untransposed weights), TN = (true, true: weight gradients)
 // PREV: 0 = C is overwritten, 1 = C += result (accumulate), 2 = C = R + result (residual)
-template <bool A_COL, bool B_COL, int EPI, int PREV>
+// SPLITK: a unit of work is (output tile, K-slice); the fp32 partial tile goes to the workspace in the accumulator's own layout
+//      (unit, wave, 16x16 tile, lane: every store is one contiguous KiB) and nt4_splitk_reduce_kernel finishes the tile
+template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK = false>
 __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, int tiles_n, int64_t K, const bf16_t* __restrict__ A,
                                                                   int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                                   bf16_t* __restrict__ C, int64_t ldc, const bf16_t* __restrict__ R,
-                                                                  float alpha, const float* __restrict__ alpha_dev, EpiArgs ea, int slot) {  // slot < 0: static tile order
+                                                                  float alpha, const float* __restrict__ alpha_dev, EpiArgs ea, int slot,  // slot < 0: static tile order
+                                                                  int splits, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntiles = tiles_m * tiles_n, G = (int)gridDim.x;
-    const int nk = (int)(K / BK);  // even, >= 4
+    const int ntiles_out = tiles_m * tiles_n;
+    const int ntiles = SPLITK ? ntiles_out * splits : ntiles_out;  // units of work
+    const int G = (int)gridDim.x;
+    const int nk_total = (int)(K / BK);  // even, >= 4 (per K-slice when SPLITK)
+    // K-steps [k_lo, k_hi) of unit t (slice boundaries rounded to even step counts)
+    auto k_lo = [&](int t) { return SPLITK ? (int)(((int64_t)nk_total * (t / ntiles_out) / splits) & ~1LL) : 0; };
+    auto k_hi = [&](int t) { return SPLITK ? ((t / ntiles_out) + 1 == splits ? nk_total : (int)(((int64_t)nk_total * (t / ntiles_out + 1) / splits) & ~1LL)) : nk_total; };
 
     // ---- tile scheduler: workgroups draw tiles from the contiguous span of their XCD (operand panels stay in that XCD's L2) and,
     // once it is empty, from the other spans.  Dynamic rather than "tile b, b+G, ...": a workgroup that starts late, or not at all,
@@ -570,18 +578,20 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     auto tileB = [&](int buf) { return smem + 2 * TILE_BYTES + buf * TILE_BYTES; };
 
     // ---- load side: (lv, lkt) = output tile and K-tile of the next fetch ------------------------------------------------
-    int lkt = 0;
+    int lkt = 0, lnk = nk_total;  // K-step of the next fetch inside its unit, K-steps of that unit
     const bf16_t* baseA = A;
     const bf16_t* baseB = B;
+    const int64_t kstepA_ = A_COL ? BK * lda : BK, kstepB_ = B_COL ? BK * ldb : BK;
     auto set_load_tile = [&](int t) {
         int tm, tn;
-        tile_from_t(t, tiles_m, tiles_n, tm, tn);
-        baseA = A_COL ? A + (int64_t)tm * BM : A + (int64_t)tm * BM * lda;
+        tile_from_t(SPLITK ? t % ntiles_out : t, tiles_m, tiles_n, tm, tn);
+        baseA = (A_COL ? A + (int64_t)tm * BM : A + (int64_t)tm * BM * lda) + k_lo(t) * kstepA_;
         // SwiGLU forward: the 256 tile columns are [gate 0..63 | up 0..63 | gate 64..127 | up 64..127] of 128 W13 column pairs
-        baseB = B_COL ? B + (int64_t)tn * BN : B + (int64_t)tn * (EPI == EPI_SWIGLU_FWD ? BN / 2 : BN) * ldb;
+        baseB = (B_COL ? B + (int64_t)tn * BN : B + (int64_t)tn * (EPI == EPI_SWIGLU_FWD ? BN / 2 : BN) * ldb) + k_lo(t) * kstepB_;
+        lnk = k_hi(t) - k_lo(t);
     };
     auto advance = [&]() {
-        if (++lkt == nk) {  // the fetches run at most 3 K-steps ahead of the MFMAs: this is always the switch to tile `nxt`
+        if (++lkt == lnk) {  // the fetches run at most 3 K-steps ahead of the MFMAs: this is always the switch to tile `nxt`
             lkt = 0;
             if (nxt >= 0) set_load_tile(nxt);  // after the last tile: keep re-fetching valid memory, never consumed
         }
@@ -596,7 +606,7 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     };
     const int offA0 = lane_off(A_COL, lda, 0), offA1 = A_COL ? lane_off(true, lda, 1) : offA0;
     const int offB0 = lane_off(B_COL, ldb, 0), offB1 = B_COL ? lane_off(true, ldb, 1) : offB0;
-    const int64_t kstepA = A_COL ? BK * lda : BK, kstepB = B_COL ? BK * ldb : BK;  // elements per K-step: added to the (64-bit) buffer base
+    const int64_t kstepA = kstepA_, kstepB = kstepB_;  // elements per K-step: added to the (64-bit) buffer base
     auto pieceA = [&](int p) { return A_COL ? (int)(p * 8 * lda * 2) : (int)(p * 32 * lda * 2); };
     auto pieceB = [&](int p) {
         if (B_COL) return (int)(p * 8 * ldb * 2);
@@ -697,7 +707,7 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
         advance();
     };
     set_load_tile(cur >= 0 ? cur : 0);
-    if (nk == 0) return;  // (never: keeps the scheduler state below out of a degenerate launch)
+    if (nk_total == 0) return;  // (never: keeps the scheduler state below out of a degenerate launch)
     fetch_step(ra0, rb0);
 #pragma unroll
     for (int p = 0; p < 8; ++p) lwriteA(tileA(0), p, ra0[p]);
@@ -714,7 +724,8 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     const int g = lane >> 4;
     while (cur >= 0) {
         int tm, tn;
-        tile_from_t(cur, tiles_m, tiles_n, tm, tn);
+        tile_from_t(SPLITK ? cur % ntiles_out : cur, tiles_m, tiles_n, tm, tn);
+        const int nk = k_hi(cur) - k_lo(cur);
         using B0_ = std::integral_constant<int, 0>;
         using B1_ = std::integral_constant<int, 1>;
         // the tile after next is requested now and read after the epilogue: the answer is the oldest vector-memory operation in
@@ -760,6 +771,24 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
                 hi[d] = (unsigned)__builtin_amdgcn_update_dpp((int)ob[d], (int)oa[d], 0x108 /* row_shl:8 */, 0xF, 0x3, false);
             }
         };
+        if constexpr (SPLITK) {
+            // fp32 partial tile, accumulator layout: [unit][wave][i*8 + j][lane] x f32x4, one contiguous KiB per store
+            const __amdgpu_buffer_rsrc_t rsS = make_rsrc(slabs + ((int64_t)cur * 4 + wave) * (64 * 64 * 4));
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    u32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float f;
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(f) : "a"(acc[j][i][r]));
+                        v[r] = __builtin_bit_cast(unsigned, f);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsS, lane * 16, (i * 8 + j) * 1024, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        } else {
         const int64_t row0 = (int64_t)tm * BM + wm * NT4_WM;
         // lane -> (row within an 8-row group, column within a 64-column duo)
         const int lane_row = lane & 7, lane_col = ((lane >> 3) & 1) * 32 + (g & 1) * 16 + (g >> 1) * 8;
@@ -881,6 +910,7 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
         };
         if (al == 1.f) epilogue(std::false_type{});
         else epilogue(std::true_type{});
+        }
         cur = nxt;
         if (cur >= 0) nxt = receive_tile();
         // the first fragments of the next tile (its K-step 0 sits in LDS buffer 0) are read again here rather than kept live
@@ -896,10 +926,72 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     }
 }
 
-template <bool A_COL, bool B_COL, int EPI, int PREV>
+// Finishes split-K tiles: one wave per (output tile, wave of the GEMM workgroup, m-tile i, 64-column duo).  Sums the K-slices'
+// partials (contiguous KiB reads), then the same rounding points and the same full-line stores as the direct epilogue:
+// C = (accumulate ? C : 0) + bf16(alpha * sum).
+__global__ __launch_bounds__(256) void nt4_splitk_reduce_kernel(const float* __restrict__ slabs, int splits, int tiles_m, int tiles_n,
+                                                                bf16_t* __restrict__ C, int64_t ldc, float alpha,
+                                                                const float* __restrict__ alpha_dev, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (tile, wave, i, jd)
+    const int ntiles = tiles_m * tiles_n;
+    if (u >= (int64_t)ntiles * 64) return;
+    const int jd = (int)(u & 1), i = (int)((u >> 1) & 7), wave = (int)((u >> 4) & 3), t = (int)(u >> 6);
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4;
+    int tm, tn;
+    tile_from_t(t, tiles_m, tiles_n, tm, tn);
+    const float al = alpha * (alpha_dev ? *alpha_dev : 1.f);
+    f32x4 sum[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) {
+        const float* p = slabs + (((int64_t)s * ntiles + t) * 4 + wave) * (64 * 64 * 4) + (int64_t)(i * 8 + jd * 4) * 256 + lane * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + j * 256);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[j][r] += v[r];
+        }
+    }
+    auto pair = [&](const f32x4& a, const f32x4& b) {
+        bf16x4 x, y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { x[r] = (bf16_t)(a[r] * al); y[r] = (bf16_t)(b[r] * al); }
+        const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(xu[0], yu[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(xu[1], yu[1], false, false);
+        u32x4 o;
+        o[0] = s0[0]; o[1] = s1[0]; o[2] = s0[1]; o[3] = s1[1];
+        return o;
+    };
+    const u32x4 oa = pair(sum[0], sum[1]), ob = pair(sum[2], sum[3]);
+    u32x4 lo, hi;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        lo[d] = (unsigned)__builtin_amdgcn_update_dpp((int)oa[d], (int)ob[d], 0x118 /* row_shr:8 */, 0xF, 0xC, false);
+        hi[d] = (unsigned)__builtin_amdgcn_update_dpp((int)ob[d], (int)oa[d], 0x108 /* row_shl:8 */, 0xF, 0x3, false);
+    }
+    const int lane_row = lane & 7, lane_col = ((lane >> 3) & 1) * 32 + (g & 1) * 16 + (g >> 1) * 8;
+    bf16_t* base = C + ((int64_t)tm * BM + wm * NT4_WM + i * 16 + lane_row) * ldc + (int64_t)tn * BN + wn * NT4_WN + jd * 64 + lane_col;
+    auto finish = [&](u32x4 o, bf16_t* dst) {
+        if (accumulate) {
+            bf16x8 ob8 = __builtin_bit_cast(bf16x8, o);
+            const bf16x8 c = *reinterpret_cast<const bf16x8*>(dst);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ob8[e] = (bf16_t)((float)ob8[e] + (float)c[e]);
+            o = __builtin_bit_cast(u32x4, ob8);
+        }
+        *reinterpret_cast<u32x4*>(dst) = o;
+    };
+    finish(lo, base);
+    finish(hi, base + 8 * ldc);
+}
+
+template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK = false>
 int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-               const void* R, float alpha, const float* alpha_dev, hipStream_t st, EpiArgs ea = EpiArgs{nullptr, 0, nullptr, 0, 0}) {
-    auto kern = gemm_nt4_kernel<A_COL, B_COL, EPI, PREV>;
+               const void* R, float alpha, const float* alpha_dev, hipStream_t st, EpiArgs ea = EpiArgs{nullptr, 0, nullptr, 0, 0},
+               int splits = 1, float* slabs = nullptr) {
+    auto kern = gemm_nt4_kernel<A_COL, B_COL, EPI, PREV, SPLITK>;
     static bool attr_set = false;  // per instantiation
     static int num_cu = 256;
     if (!attr_set) {
@@ -911,11 +1003,11 @@ int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, 
             num_cu = prop.multiProcessorCount;
         attr_set = true;
     }
-    const int ntiles = tiles_m * tiles_n;
+    const int ntiles = tiles_m * tiles_n * (SPLITK ? splits : 1);
     int grid = ntiles < num_cu ? ntiles : num_cu;
     const int slot = g_nt4_dynamic.load(std::memory_order_relaxed) ? (int)(nt4_next_slot() & 15) : -1;  // consecutive launches: different slots
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT4_THREADS), NT4_LDS_BYTES, st, tiles_m, tiles_n, K, (const bf16_t*)A, lda,
-                       (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (const bf16_t*)R, alpha, alpha_dev, ea, slot);
+                       (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (const bf16_t*)R, alpha, alpha_dev, ea, slot, splits, slabs);
     SSI_LAUNCH_CHECK();
     return SSI_OK;
 }
@@ -977,6 +1069,15 @@ int ssi_gemm_mfma_bf16_splitk(int layout, int64_t M, int64_t N, int64_t K, const
                               int accumulate, int splits, float* slabs, void* stream) {
     const int tm = (int)(M / BM), tn = (int)(N / BN);
     auto st = (hipStream_t)stream;
+    // weight-gradient form on the persistent kernel: units = tile x K-slice, every slice at least 6 K-steps, no residual
+    if (layout == SSI_GEMM_TN && nt4_ok(K) && nt4_ld_ok(lda, ldb) && !R && K / BK / splits >= 6 && ldc % 8 == 0) {
+        if (int rc = launch_nt4<true, true, EPI_PLAIN, 0, true>(tm, tn, K, A, lda, B, ldb, C, ldc, nullptr, 1.f, nullptr, st,
+                                                                 EpiArgs{nullptr, 0, nullptr, 0, 0}, splits, slabs)) return rc;
+        hipLaunchKernelGGL(nt4_splitk_reduce_kernel, dim3((unsigned)ssi_cdiv((int64_t)tm * tn * 64, 4)), dim3(256), 0, st, slabs, splits, tm, tn,
+                           (bf16_t*)C, ldc, alpha, alpha_dev, accumulate);
+        SSI_LAUNCH_CHECK();
+        return SSI_OK;
+    }
 #define GO(AC, BC) return launch<AC, BC, true>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, accumulate, st, splits, slabs)
     switch (layout) {
         case SSI_GEMM_NT: GO(false, false);

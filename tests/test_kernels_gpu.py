@@ -591,6 +591,31 @@ def test_gemm_splitk_matches_direct(ops, layout, splits):
     assert ops.splitk_choice(2048, 2048, 16384) > 1 and ops.splitk_choice(16384, 2048, 16384) == 1
 
 
+@pytest.mark.parametrize("splits", [2, 3, 4, 8])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_gemm_splitk_weight_gradient_on_the_persistent_kernel(ops, splits, accumulate):
+    """Weight-gradient (TN) split-K with slices long enough for the persistent kernel (units = tile x K-slice, fp32 partials in
+    the accumulator layout, nt4_splitk_reduce_kernel): exact on small integers whatever the slicing; close to the unsplit GEMM."""
+    M, N, K = 768, 512, 4096   # 6 tiles x splits units; 64 K-steps: slices of 32 / 20-22-22 / 16 / 8
+    a, b = _gemm_operands(2, M, N, K, torch.bfloat16, 91, integer=True)
+    a, b = a.to(DEV), b.to(DEV)
+    c0 = torch.randint(-3, 4, (M, N), generator=torch.Generator().manual_seed(92)).to(torch.bfloat16).to(DEV)
+    ws = torch.empty(splits * M * N, dtype=torch.float32, device=DEV)
+    c = c0.clone() if accumulate else torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm_splitk(2, a, b, c, splits, ws, alpha=0.125, accumulate=accumulate)
+    ref = (a.float().t() @ b.float()) * 0.125
+    exact = ref.abs() <= 256
+    want = ref.bfloat16().float() + (c0.float() if accumulate else 0)
+    assert torch.equal(c.float()[exact], want.bfloat16().float()[exact])
+    a2, b2 = _gemm_operands(2, M, N, K, torch.bfloat16, 93)
+    direct = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    split = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(2, a2.to(DEV), b2.to(DEV), direct)
+    ops.gemm_splitk(2, a2.to(DEV), b2.to(DEV), split, splits, ws)
+    diff = (split.float() - direct.float()).abs()
+    assert float(diff.max()) <= 2 ** -6 * float(direct.float().abs().max())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,cols", [(64, 64), (200, 136), (2048, 3072)])
 def test_transpose(ops, dtype, rows, cols):
