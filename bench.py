@@ -206,6 +206,9 @@ def main() -> int:
     ap.add_argument("--packed", action="store_true",
                     help="secondary workload (BASELINE config E at one GPU): rows packed with ~440-1100-token documents, block-causal "
                          "attention; use with --seq 8192 --batch 2.  Not the headline line.")
+    ap.add_argument("--padded", action="store_true",
+                    help="secondary workload (SURVEY.md §8d): sequence lengths ~U(0.4 S, S), right-padded to the batch maximum; "
+                         "tokens/s then counts NON-PAD tokens.  Not the headline line.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timing", action="store_true")
     args = ap.parse_args()
@@ -258,8 +261,8 @@ def main() -> int:
         batches = [{k: (v.to(device) if torch.is_tensor(v) else v)
                     for k, v in synthetic_packed_batch(args.batch, args.seq, args.n_dsus, seed=42_831 + i, rank=rank).items()} for i in range(min(n_total, 4))]
     else:
-        batches = [{k: v.to(device) for k, v in synthetic_batch(args.batch, args.seq, args.n_dsus, rank=rank, index=i % 4).items()}
-                   for i in range(min(n_total, 4))]
+        batches = [{k: v.to(device) for k, v in synthetic_batch(args.batch, args.seq, args.n_dsus, rank=rank, index=i % 4,
+                                                                fixed_len=not args.padded).items()} for i in range(min(n_total, 4))]
     timer = GemmTimer()
     if not args.no_gemm_timing and rank == 0:
         timer.install()
@@ -302,6 +305,8 @@ def main() -> int:
         elapsed = float(t.item())
 
     tokens_per_step = args.batch * args.seq * world
+    if args.padded:  # non-pad tokens actually processed in the timed steps (all ranks draw the same length distribution)
+        tokens_per_step = world * sum(int((batches[(args.warmup + i) % len(batches)]["tokens"] != pad_id).sum()) for i in range(args.steps)) / args.steps
     value = tokens_per_step * args.steps / elapsed
     f_tok = flops_per_token(lcfg.vocab_size, args.seq, layers=args.layers) if args.layers == 16 else None
     if args.packed and f_tok:  # attention term over the documents instead of the whole row
@@ -318,7 +323,8 @@ def main() -> int:
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"Llama-3.2-1B +{args.n_dsus} DSUs (V={lcfg.vocab_size}), SFT step fwd+bwd+AdamW, seq_len={args.seq}, "
                                    f"batch={args.batch}/GPU, grad_accum=1, {args.layers} layers, random-init weights, MLS-shaped synthetic DSU sequences"
-                                   + (", rows packed with 440-1100-token documents (block-causal attention)" if args.packed else ""),
+                                   + (", rows packed with 440-1100-token documents (block-causal attention)" if args.packed else "")
+                                   + (", lengths ~U(0.4 S, S) right-padded, non-pad tokens counted" if args.padded else ""),
                        "global_batch": args.batch * world, "seq_len": args.seq, "parallelism": f"dp{world}", "last_loss": loss},
         }
         if f_tok:

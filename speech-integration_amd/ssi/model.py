@@ -303,8 +303,8 @@ class HipLlamaDecoder(nn.Module):
         if not self._mfma_shapes():
             return seq
         g = 256 // math.gcd(batch, 256)
-        g = max(g, 64)
-        return _align(seq, g)
+        g = max(g, 128)  # 128: the MFMA attention kernels walk 128-key groups (a ragged batch maximum would otherwise drop to the
+        return _align(seq, g)  # generic attention kernels, 5x slower end to end)
 
     # ---- forward: decoder stack --------------------------------------------------------------------------------------
     @staticmethod
