@@ -499,13 +499,19 @@ class HipLlamaDecoder(nn.Module):
         """Logits.  ``num_output_chunks > 0``: list of [B, ceil(S/n), V] chunks in the model dtype (torch.chunk rule,
         SURVEY.md Appendix A.4); else one fp32 [B, S, V] tensor — as torchtune's ``TransformerDecoder.forward``."""
         tokens = self._check_inputs(tokens, mask, encoder_input, encoder_mask, input_pos)
-        B, S = tokens.shape
+        B, S0 = tokens.shape
+        S = self.padded_seq_len(B, S0)
+        if S != S0:  # right-pad to whole MFMA tiles (inert under causal attention), slice the logits back below
+            tokens = torch.cat([tokens, torch.zeros(B, S - S0, dtype=tokens.dtype, device=tokens.device)], dim=1)
+            if input_pos is not None:
+                cont = input_pos[:, -1:].to(tokens.device) + torch.arange(1, S - S0 + 1, device=tokens.device)
+                input_pos = torch.cat([input_pos.to(tokens.device), cont.clamp_(max=self._rope.shape[0] - 1)], dim=1)
         hn = self.forward_hidden(tokens, input_pos).view(B * S, self.embed_dim)
         if torch.is_grad_enabled() and self.training:
             logits = _HeadLogitsFn.apply(self, hn, self._anchor)
         else:
             logits = self._head_logits(hn)
-        logits = logits.view(B, S, self.vocab_pad)[..., : self.vocab_size]
+        logits = logits.view(B, S, self.vocab_pad)[:, :S0, : self.vocab_size]
         if self.num_output_chunks > 0:
             return list(logits.chunk(self.num_output_chunks, dim=1))
         return logits.float()
