@@ -535,7 +535,9 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     const int xcd = (int)blockIdx.x & 7, span_q = ntiles >> 3, span_r = ntiles & 7;
     auto span_len = [&](int x) { return span_q + (x < span_r ? 1 : 0); };
     auto span_lo = [&](int x) { return x < span_r ? x * (span_q + 1) : span_r * (span_q + 1) + (x - span_r) * span_q; };
-    auto span_fixed = [&](int x) { const int n = (G - x + 7) >> 3; return n < span_len(x) ? n : span_len(x); };  // tiles given out statically
+    // the first two tiles of every workgroup are fixed (no atomic in the prologue; shapes of up to two rounds never use the counters)
+    auto span_wgs = [&](int x) { return (G - x + 7) >> 3; };  // workgroups whose blockIdx maps to XCD x
+    auto span_fixed = [&](int x) { const int n = 2 * span_wgs(x); return n < span_len(x) ? n : span_len(x); };
     // slot < 0 = static order (tile index += G/8 within the span): optimal when every workgroup has its CU from the start, since
     // equal tiles then need no balancing and a greedy scheduler can only hurt (a workgroup that is a little early takes a third
     // tile where everybody should do two: measured -3..-12 % on the 2-3-round shapes).  The trainer switches to the dynamic
@@ -556,11 +558,16 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
             int t = -1;
             const int i = pending + span_fixed(xcd);
             if (i < span_len(xcd)) t = span_lo(xcd) + i;
-            for (int k = 1; k < 8 && t < 0; ++k) {  // own span empty: take from the others (only at the very end of a launch)
-                const int x = (xcd + k) & 7;
-                if (span_fixed(x) >= span_len(x)) continue;
-                const int j = atomicAdd(&sched[x], 1) + span_fixed(x);
-                if (j < span_len(x)) t = span_lo(x) + j;
+            if (t < 0) {  // own span empty: take from the others (only at the very end of a launch); one look at all the counters
+                int seen[8];  // first, so that a finished launch costs one load instead of seven atomic round trips
+#pragma unroll
+                for (int x = 0; x < 8; ++x) seen[x] = __hip_atomic_load(&sched[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int k = 1; k < 8 && t < 0; ++k) {
+                    const int x = (xcd + k) & 7;
+                    if (seen[x] + span_fixed(x) >= span_len(x)) continue;
+                    const int j = atomicAdd(&sched[x], 1) + span_fixed(x);
+                    if (j < span_len(x)) t = span_lo(x) + j;
+                }
             }
             *lds_next = t;
         }
@@ -569,7 +576,10 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     };
     int cur = ((int)blockIdx.x >> 3) < span_len(xcd) ? span_lo(xcd) + ((int)blockIdx.x >> 3) : -1;
     int nxt = -1;
-    if (cur >= 0) request_tile();  // answered while the first operands are on their way
+    if (dynamic) {
+        const int second = ((int)blockIdx.x >> 3) + span_wgs(xcd);
+        nxt = (cur >= 0 && second < span_len(xcd)) ? span_lo(xcd) + second : -1;
+    }
 
     f32x4 acc[8][8];  // [j (n-tile)][i (m-tile)], defined by the zero-C MFMAs of each tile's first K-step
     // LDS: [A buf 0 | A buf 1 | B buf 0 | B buf 1]; with the buffer index a compile-time constant every fragment address is one
@@ -718,7 +728,7 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int q = 0; q < 4; ++q) { rdA1(S0[q], tileA(0), 0, 0, q); rdB1(S1[q], tileB(0), 0, 0, q); }
-    if (cur >= 0) nxt = receive_tile();
+    if (cur >= 0 && !dynamic) nxt = receive_tile();
 
     const float al = alpha * (alpha_dev ? *alpha_dev : 1.f);
     const int g = lane >> 4;
