@@ -25,6 +25,7 @@ for _p in (ROOT, PKG):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before any HIP call: RCCL needs dmabuf IPC on this driver
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -34,6 +34,7 @@ def init_distributed(device: torch.device, timeout_s: int = 600) -> tuple[int, i
         return 1, 0
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's peer mappings fail with the legacy mode on this driver
         backend = os.environ.get("SSI_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
         kwargs = {}
         if device.type == "cuda" and backend == "nccl":
