@@ -246,33 +246,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     if (h == 0) lse[((int64_t)b * H + head) * S + qg] = m + logf(ltot);
 }
 
-// =====================================================================================================================
-// backward: delta = rowsum(dO * O)
-// =====================================================================================================================
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
-                                                         float* __restrict__ delta, int64_t rows, int S, int H) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (row, head, 8-element chunk)
-    const int64_t rh = g >> 3;
-    if (rh >= rows * H) return;
-    const int64_t row = rh / H;
-    const int head = (int)(rh % H);
-    const int64_t off = rh * HD + (g & 7) * 8;
-    bf16x8 a = *reinterpret_cast<const bf16x8*>(out + off), c = *reinterpret_cast<const bf16x8*>(dout + off);
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)c[j];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if ((g & 7) == 0) delta[((row / S) * H + head) * S + (row % S)] = s;
-}
 
 // =====================================================================================================================
 // backward: dQ   (same decomposition as the forward)
 // =====================================================================================================================
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                          const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
+                                                          float* __restrict__ delta, bf16_t* __restrict__ dqkv,
                                                           const int32_t* __restrict__ doc_start, int S, int H, int KV) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 2 * 8192];  // ring of 3 x [K | V][64][64] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -306,7 +286,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         }
     }
     const float lq = lse[((int64_t)b * H + head) * S + qg];
-    const float dl = delta[((int64_t)b * H + head) * S + qg];
+    // delta = rowsum(dO * O) of this lane's query row: each half-wave holds half of the row (the dO fragments are already here);
+    // written out for the dK/dV kernel, which runs after this one (every (row, head) belongs to exactly one wave)
+    float dl = 0.f;
+    {
+        const bf16_t* orow = out + (row0 + qg) * ((int64_t)H * HD) + (int64_t)head * HD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(orow + 16 * ks);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += (float)of[j] * (float)dof[ks][j];
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        if (h == 0) delta[((int64_t)b * H + head) * S + qg] = dl;
+    }
     f32x16 dq[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -568,12 +561,8 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
                       void* stream) {
     auto st = (hipStream_t)stream;
     const int rep = n_heads / n_kv, qpw = 4 / rep;
-    const int64_t rows = batch * seq;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)ssi_cdiv(rows * n_heads * 8, 256)), dim3(256), 0, st, (const bf16_t*)out,
-                       (const bf16_t*)dout, delta, rows, (int)seq, n_heads);
-    SSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * n_kv * (seq / (32 * qpw)))), dim3(256), 0, st, (const bf16_t*)qkv,
-                       ld, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_start, (int)seq, n_heads, n_kv);
+                       ld, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_start, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(batch * n_kv * (seq / 128))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
                        (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, (int)seq, n_heads, n_kv);
