@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SSI_ABI_VERSION 2 /* 2: + ssi_attn_varlen_fwd/bwd, ssi_set_gemm_tile_order, NN form of ssi_gemm_swiglu_bwd */
+#define SSI_ABI_VERSION 2 /* 2: + ssi_attn_varlen_fwd/bwd(_rope), ssi_set_gemm_tile_order, NN form of ssi_gemm_swiglu_bwd */
 
 enum { SSI_F32 = 0, SSI_BF16 = 1 };
 enum { SSI_OK = 0, SSI_ERR_ARG = 1, SSI_ERR_UNSUPPORTED = 2, SSI_ERR_WORKSPACE = 3, SSI_ERR_HIP = 1000 /* + hipError_t */ };
@@ -97,6 +97,13 @@ int ssi_attn_varlen_fwd(const void* qkv, int64_t ld, void* out, float* lse, cons
 int ssi_attn_varlen_bwd(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
                         float* delta, const int32_t* doc_start, const int32_t* doc_end, int64_t batch, int64_t seq,
                         int n_heads, int n_kv, int head_dim, int dtype, void* stream);
+
+/* Same, followed by the backward of the RoPE rotation on the q and k heads of dqkv (= ssi_rope_inplace(dqkv, ..., inverse=1)): the
+ * MFMA kernels apply it in their epilogues, which saves a pass over dqkv.  rope_table / table_len / positions as in ssi_rope_inplace. */
+int ssi_attn_varlen_bwd_rope(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
+                             float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope_table,
+                             int64_t table_len, const int32_t* positions, int64_t batch, int64_t seq, int n_heads, int n_kv,
+                             int head_dim, int dtype, void* stream);
 
 /* ---- K7  SwiGLU elementwise (torchtune FeedForward: w2(silu(w1 x) * w3 x)) ------------------------------------------ */
 /* gu: [rows, 2*inter] = [gate | up]; act[rows, inter] = silu(gate) * up */

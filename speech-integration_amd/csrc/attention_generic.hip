@@ -13,8 +13,10 @@ bool ssi_attn_mfma_supported(int64_t ld, int64_t batch, int64_t seq, int n_heads
 int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, const int32_t* doc_start, int64_t batch, int64_t seq,
                       int n_heads, int n_kv, void* stream);
 int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
-                      float* delta, const int32_t* doc_start, const int32_t* doc_end, int64_t batch, int64_t seq, int n_heads,
-                      int n_kv, void* stream);
+                      float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope, const int32_t* positions,
+                      int64_t batch, int64_t seq, int n_heads, int n_kv, void* stream);
+extern "C" int ssi_rope_inplace(void* x, int64_t ld, int64_t rows, int64_t seq_len, int n_heads_rot, int head_dim, const float* table,
+                                int64_t table_len, const int32_t* positions, int inverse, int dtype, void* stream);
 
 template <typename T, int HD>
 __device__ __forceinline__ void load_row(const T* p, float (&r)[HD]) {
@@ -230,16 +232,20 @@ extern "C" int ssi_attn_varlen_fwd(const void* qkv, int64_t ld, void* out, float
     return SSI_OK;
 }
 
-extern "C" int ssi_attn_varlen_bwd(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
-                                   float* delta, const int32_t* doc_start, const int32_t* doc_end, int64_t batch, int64_t seq,
-                                   int n_heads, int n_kv, int head_dim, int dtype, void* stream) {
+// rope_table != NULL: dqkv's q and k heads are returned in pre-RoPE space, i.e. followed by ssi_rope_inplace(inverse) — inside the
+// MFMA kernels' epilogues, as a second launch on the generic path.
+static int attn_varlen_bwd_impl(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
+                                float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope_table,
+                                int64_t table_len, const int32_t* positions, int64_t batch, int64_t seq, int n_heads, int n_kv,
+                                int head_dim, int dtype, void* stream) {
     if (int rc = attn_check(qkv, ld, batch, seq, n_heads, n_kv, head_dim)) return rc;
     SSI_CHECK_ARG(out && dout && lse && dqkv && delta && ((doc_start == nullptr) == (doc_end == nullptr)));
     if (batch * seq == 0) return SSI_OK;
     const bool fast = ssi_attn_mfma_supported(ld, batch, seq, n_heads, n_kv, head_dim, dtype);
     if ((ssi_get_impl() == SSI_IMPL_MFMA || ssi_get_impl() == SSI_IMPL_MFMA_WG8) && !fast) { ssi_set_error("ssi_attn_bwd: MFMA path forced but unsupported shape"); return SSI_ERR_UNSUPPORTED; }
     if (fast && ssi_get_impl() != SSI_IMPL_GENERIC)
-        return ssi_attn_bwd_mfma(qkv, ld, out, dout, lse, dqkv, delta, doc_start, doc_end, batch, seq, n_heads, n_kv, stream);
+        return ssi_attn_bwd_mfma(qkv, ld, out, dout, lse, dqkv, delta, doc_start, doc_end, rope_table, positions, batch, seq, n_heads, n_kv,
+                                 stream);
     auto st = (hipStream_t)stream;
     const int64_t nq = batch * n_heads * seq, nk = batch * n_kv * seq;
     SSI_DISPATCH_DTYPE(dtype, ATTN_HD_SWITCH(head_dim, {
@@ -253,7 +259,25 @@ extern "C" int ssi_attn_varlen_bwd(const void* qkv, int64_t ld, const void* out,
                            ld, (const T*)dout, lse, delta, (T*)dqkv, doc_end, batch, seq, n_heads, n_kv);
     }));
     SSI_LAUNCH_CHECK();
+    if (rope_table)
+        return ssi_rope_inplace(dqkv, ld, batch * seq, seq, n_heads + n_kv, head_dim, rope_table, table_len, positions, 1, dtype, stream);
     return SSI_OK;
+}
+
+extern "C" int ssi_attn_varlen_bwd(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
+                                   float* delta, const int32_t* doc_start, const int32_t* doc_end, int64_t batch, int64_t seq,
+                                   int n_heads, int n_kv, int head_dim, int dtype, void* stream) {
+    return attn_varlen_bwd_impl(qkv, ld, out, dout, lse, dqkv, delta, doc_start, doc_end, nullptr, 0, nullptr, batch, seq, n_heads, n_kv,
+                                head_dim, dtype, stream);
+}
+
+extern "C" int ssi_attn_varlen_bwd_rope(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
+                                        float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope_table,
+                                        int64_t table_len, const int32_t* positions, int64_t batch, int64_t seq, int n_heads, int n_kv,
+                                        int head_dim, int dtype, void* stream) {
+    SSI_CHECK_ARG(rope_table != nullptr && (positions != nullptr || table_len >= seq));
+    return attn_varlen_bwd_impl(qkv, ld, out, dout, lse, dqkv, delta, doc_start, doc_end, rope_table, table_len, positions, batch, seq,
+                                n_heads, n_kv, head_dim, dtype, stream);
 }
 
 

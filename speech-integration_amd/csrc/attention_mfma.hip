@@ -28,6 +28,20 @@ namespace {
 // Workgroup barrier for the LDS-DMA rings.  __syncthreads() would do, except that hipcc puts `s_waitcnt vmcnt(0)` in front of
 // its s_barrier: that waits for the prefetches of the NEXT steps as well and exposes their whole memory latency every step.
 // Here the counted vmcnt wait for this step's pieces is written out by the caller; only LDS traffic is drained.
+// Backward of the interleaved RoPE on the 4 consecutive head dimensions d0 .. d0+3 of one row (two adjacent pairs), applied to
+// the gradient AFTER its rounding to bf16 and rounded again, i.e. exactly what ssi_rope_inplace(inverse) does to the stored
+// tensor (torchtune applies RoPE as a separate bf16 -> fp32 -> bf16 op).  tb = table row of the position: [hd/2][cos, sin].
+__device__ __forceinline__ bf16x4 unrope4(bf16x4 v, const float* __restrict__ tb, int d0) {
+    const f32x4 cs = *reinterpret_cast<const f32x4*>(tb + d0);  // (cos, sin) of pairs d0/2 and d0/2 + 1
+    const float x0 = (float)v[0], x1 = (float)v[1], x2 = (float)v[2], x3 = (float)v[3];
+    bf16x4 o;
+    o[0] = (bf16_t)(x0 * cs[0] + x1 * cs[1]);
+    o[1] = (bf16_t)(x1 * cs[0] - x0 * cs[1]);
+    o[2] = (bf16_t)(x2 * cs[2] + x3 * cs[3]);
+    o[3] = (bf16_t)(x3 * cs[2] - x2 * cs[3]);
+    return o;
+}
+
 __device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int HD = 64;
@@ -253,7 +267,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, bf16_t* __restrict__ dqkv,
-                                                          const int32_t* __restrict__ doc_start, int S, int H, int KV) {
+                                                          const int32_t* __restrict__ doc_start, const float* __restrict__ rope,
+                                                          const int32_t* __restrict__ positions, int S, int H, int KV) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 2 * 8192];  // ring of 3 x [K | V][64][64] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep = H / KV, qpw = 4 / rep;
@@ -360,6 +375,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         if (t + 2 < nt) tile_step(t + 2, std::integral_constant<int, 2>{});
     }
     bf16_t* drow = dqkv + (row0 + qg) * ld + (int64_t)head * HD;
+    // rope != NULL: the gradient leaves in pre-RoPE space (backward of the rotation fused here, saves a pass over dqkv)
+    const float* tb = rope ? rope + (int64_t)(positions ? positions[row0 + qg] : qg) * HD : nullptr;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -367,6 +384,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
             bf16x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(dq[db][4 * g + e] * 0.125f);
+            if (tb) v = unrope4(v, tb, db * 32 + 8 * g + 4 * h);
             *reinterpret_cast<bf16x4*>(drow + db * 32 + 8 * g + 4 * h) = v;
         }
 }
@@ -383,7 +401,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
-                                                           const int32_t* __restrict__ doc_end, int S, int H, int KV) {
+                                                           const int32_t* __restrict__ doc_end, const float* __restrict__ rope,
+                                                           const int32_t* __restrict__ positions, int S, int H, int KV) {
     // ring of RING step buffers: [Q tile 4 KiB | dO tile 4 KiB | lse 128 B | delta 128 B]; requests run RING-1 steps ahead
     constexpr int SB = 8192 + 256;
     constexpr int RING = DKV_RING;
@@ -519,6 +538,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
     // lane = key, registers = d (runs of 4): 8-byte stores into the k and v column blocks of dqkv
     bf16_t* krow_out = dqkv + (row0 + kg) * ld + (int64_t)H * HD + (int64_t)kvh * HD;
     bf16_t* vrow_out = krow_out + (int64_t)KV * HD;
+    const float* tb = rope ? rope + (int64_t)(positions ? positions[row0 + kg] : kg) * HD : nullptr;  // dK leaves in pre-RoPE space
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -529,6 +549,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
                 vk[e] = (bf16_t)(dk[db][4 * g + e] * -0.125f);  // dk holds -sum dS Q
                 vv[e] = (bf16_t)dv[db][4 * g + e];
             }
+            if (tb) vk = unrope4(vk, tb, db * 32 + 8 * g + 4 * h);
             *reinterpret_cast<bf16x4*>(krow_out + db * 32 + 8 * g + 4 * h) = vk;
             *reinterpret_cast<bf16x4*>(vrow_out + db * 32 + 8 * g + 4 * h) = vv;
         }
@@ -557,15 +578,15 @@ int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, const 
 }
 
 int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
-                      const int32_t* doc_start, const int32_t* doc_end, int64_t batch, int64_t seq, int n_heads, int n_kv,
-                      void* stream) {
+                      const int32_t* doc_start, const int32_t* doc_end, const float* rope, const int32_t* positions, int64_t batch,
+                      int64_t seq, int n_heads, int n_kv, void* stream) {
     auto st = (hipStream_t)stream;
     const int rep = n_heads / n_kv, qpw = 4 / rep;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * n_kv * (seq / (32 * qpw)))), dim3(256), 0, st, (const bf16_t*)qkv,
-                       ld, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_start, (int)seq, n_heads, n_kv);
+                       ld, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_start, rope, positions, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(batch * n_kv * (seq / 128))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
-                       (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, (int)seq, n_heads, n_kv);
+                       (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, rope, positions, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
     return SSI_OK;
 }

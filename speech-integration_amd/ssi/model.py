@@ -437,8 +437,9 @@ class HipLlamaDecoder(nn.Module):
             wgrad(dhmid, att, f"L{l}.wo")
             dqkv = A.get("dqkv", (T, self.qkv_dim), dt)
             delta = A.get("delta", (B * H * S,), torch.float32)
-            ops.attn_bwd(qkv, att, datt, A.get(f"lse.{l}", (B * H * S,), torch.float32), dqkv, delta, B, S, H, KV, hd, ds, de)
-            ops.rope_(dqkv, S, H + KV, hd, self._rope, inverse=True, positions=pos)
+            # attention backward with the backward of the RoPE rotation fused into its epilogues: dqkv arrives in pre-RoPE space
+            ops.attn_bwd(qkv, att, datt, A.get(f"lse.{l}", (B * H * S,), torch.float32), dqkv, delta, B, S, H, KV, hd, ds, de,
+                         rope_table=self._rope, positions=pos)
             dgrad(dqkv, f"L{l}.wqkv", dxn)
             wgrad(dqkv, xn1, f"L{l}.wqkv")
             ops.rmsnorm_bwd(dxn, h_in, self._view(f"L{l}.sa_norm"), A.get(f"rstd1.{l}", (T,), torch.float32), dhmid, dh,

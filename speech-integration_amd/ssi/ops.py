@@ -106,12 +106,22 @@ def attn_fwd(qkv: Tensor, out: Tensor, lse: Tensor, batch: int, seq: int, n_head
 
 
 def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, dqkv: Tensor, delta: Tensor, batch: int, seq: int,
-             n_heads: int, n_kv: int, head_dim: int, doc_start: Optional[Tensor] = None, doc_end: Optional[Tensor] = None) -> None:
+             n_heads: int, n_kv: int, head_dim: int, doc_start: Optional[Tensor] = None, doc_end: Optional[Tensor] = None,
+             rope_table: Optional[Tensor] = None, positions: Optional[Tensor] = None) -> None:
+    """dqkv of causal (or block-causal) GQA attention.  With ``rope_table`` the q / k parts come back in pre-RoPE space (the
+    backward of ``rope_`` fused in), positions as in ``rope_``."""
     assert qkv.stride(1) == 1 and dqkv.stride() == qkv.stride() and out.is_contiguous() and dout.is_contiguous()
     assert delta.dtype == torch.float32 and delta.numel() >= batch * n_heads * seq
     ds, de = _doc_ptrs(doc_start, doc_end, batch * seq)
-    check(_lib.load().ssi_attn_varlen_bwd(ptr(qkv), qkv.stride(0), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), ds, de, batch,
-                                          seq, n_heads, n_kv, head_dim, dtype_code(qkv.dtype), stream_ptr()), "ssi_attn_varlen_bwd")
+    if rope_table is None:
+        check(_lib.load().ssi_attn_varlen_bwd(ptr(qkv), qkv.stride(0), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), ds, de, batch,
+                                              seq, n_heads, n_kv, head_dim, dtype_code(qkv.dtype), stream_ptr()), "ssi_attn_varlen_bwd")
+        return
+    assert rope_table.dtype == torch.float32 and rope_table.is_contiguous() and rope_table.shape[1] * 2 == head_dim
+    assert positions is None or (positions.dtype == torch.int32 and positions.numel() == batch * seq)
+    check(_lib.load().ssi_attn_varlen_bwd_rope(ptr(qkv), qkv.stride(0), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), ds, de,
+                                               ptr(rope_table), rope_table.shape[0], ptr(positions), batch, seq, n_heads, n_kv, head_dim,
+                                               dtype_code(qkv.dtype), stream_ptr()), "ssi_attn_varlen_bwd_rope")
 
 
 def swiglu_fwd(gu: Tensor, act: Tensor) -> None:

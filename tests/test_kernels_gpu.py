@@ -568,6 +568,44 @@ def test_attention_varlen_documents(ops, B, S, H, KV, rows):
         assert not torch.equal(out2[:n0], res[_lib.IMPL_MFMA][0][:n0])
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_attention_backward_with_fused_rope_backward(ops, packed):
+    """ssi_attn_varlen_bwd_rope == ssi_attn_varlen_bwd followed by ssi_rope_inplace(inverse) on the q / k heads: MFMA kernels
+    (rotation in the epilogues, to within one bf16 rounding of the two-step result) and generic kernels (second launch: identical)."""
+    from ssi import _lib
+    from ssi.model import llama3_rope_table
+    B, S, H, KV, hd = 2, 256, 4, 2, 64
+    qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=95).to(DEV)
+    do = rnd(B * S, H * hd, dtype=torch.bfloat16, seed=96).to(DEV)
+    table = llama3_rope_table(hd, 512, 500_000, 32).to(DEV)
+    ds = de = pos = None
+    if packed:
+        rows = [[100, 37, 119], [64, 192]]
+        ds, de = (t.to(DEV) for t in _doc_arrays(rows, S))
+        pos = torch.cat([torch.cat([torch.arange(n) for n in lens]) for lens in rows]).to(torch.int32).to(DEV)
+    for impl in (_lib.IMPL_MFMA, _lib.IMPL_GENERIC):
+        prev = ops.set_impl(impl)
+        try:
+            out = torch.empty(B * S, H * hd, dtype=torch.bfloat16, device=DEV)
+            lse = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+            ops.attn_fwd(qkv, out, lse, B, S, H, KV, hd, ds, de)
+            delta = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+            two = torch.empty_like(qkv)
+            ops.attn_bwd(qkv, out, do, lse, two, delta, B, S, H, KV, hd, ds, de)
+            ops.rope_(two, S, H + KV, hd, table, inverse=True, positions=pos)
+            one = torch.full_like(qkv, float("nan"))
+            ops.attn_bwd(qkv, out, do, lse, one, delta, B, S, H, KV, hd, ds, de, rope_table=table, positions=pos)
+        finally:
+            ops.set_impl(prev)
+        assert torch.isfinite(one).all()
+        assert torch.equal(one[:, (H + KV) * hd:], two[:, (H + KV) * hd:])        # dV is not rotated
+        if impl == _lib.IMPL_GENERIC:
+            assert torch.equal(one, two)
+        else:
+            diff = (one.float() - two.float()).abs()
+            assert float(diff.max()) <= 2 ** -7 * float(two.float().abs().max()) and float((diff > 0).float().mean()) < 0.05
+
+
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("splits", [2, 3, 8])
 def test_gemm_splitk_matches_direct(ops, layout, splits):
