@@ -77,6 +77,12 @@ int ssi_rope_inplace(void* x, int64_t ld, int64_t rows, int64_t seq_len, int n_h
                      const float* table, int64_t table_len, const int32_t* positions, int inverse, int dtype,
                      void* stream);
 
+/* C[M, N] = A[M, K] B[N, K]^T followed by ssi_rope_inplace(C, heads [0, n_heads_rot)): the QKV projection (K3) with the rotation
+ * (K4) in the GEMM epilogue on the MFMA path (bf16, head_dim 64, n_heads_rot * 64 a multiple of 256), two launches otherwise. */
+int ssi_gemm_rope(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                  int64_t seq_len, int n_heads_rot, int head_dim, const float* rope_table, int64_t table_len,
+                  const int32_t* positions, int dtype, void* stream);
+
 /* ---- K5  causal GQA attention (F.scaled_dot_product_attention(is_causal=True) inside torchtune MultiHeadAttention) -- */
 /* qkv: [B*S, ld] with q heads at column 0, k heads at n_heads*head_dim, v heads at (n_heads+n_kv)*head_dim.
  * out: [B*S, n_heads*head_dim].  lse: [B, n_heads, S] fp32 (natural-log sum-exp of scaled scores). */

@@ -69,6 +69,14 @@ template <typename T> __device__ __forceinline__ void ssi_swiglu_bwd_elem(float 
     dgate = (df * uf) * (sig * t);
 }
 
+// One RoPE pair, shared by ssi_rope_inplace and the QKV GEMM epilogue (same reason for switching contraction off; it is also
+// what the reference's unfused torch expression computes)
+__device__ __forceinline__ void ssi_rope_pair(float x0, float x1, float c, float s, float& o0, float& o1) {
+#pragma clang fp contract(off)
+    o0 = x0 * c - x1 * s;
+    o1 = x1 * c + x0 * s;
+}
+
 // 16-byte vector of storage elements: 4 floats or 8 bf16
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {

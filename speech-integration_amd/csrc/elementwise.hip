@@ -217,8 +217,10 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ x, int64_t ld
     for (int i = 0; i < N; i += 2) {
         const float c = tb[i], s = tb[i + 1] * sign;
         const float x0 = a.get(i), x1 = a.get(i + 1);
-        o.set(i, x0 * c - x1 * s);
-        o.set(i + 1, x1 * c + x0 * s);
+        float o0, o1;
+        ssi_rope_pair(x0, x1, c, s, o0, o1);
+        o.set(i, o0);
+        o.set(i + 1, o1);
     }
     store16(p, o);
 }

@@ -145,6 +145,26 @@ extern "C" int ssi_gemm_splitk(int layout, int64_t M, int64_t N, int64_t K, cons
                                      (float*)workspace, stream);
 }
 
+// ---- QKV projection + RoPE (K3 + K4): C = A B^T, then the interleaved rotation on the first rot_heads heads of every row --------
+bool ssi_gemm_rope_mfma(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                        const float* rope, const int32_t* positions, int64_t seq, int64_t rot_cols, void* stream, int* rc);
+extern "C" int ssi_rope_inplace(void* x, int64_t ld, int64_t rows, int64_t seq_len, int n_heads_rot, int head_dim, const float* table,
+                                int64_t table_len, const int32_t* positions, int inverse, int dtype, void* stream);
+
+extern "C" int ssi_gemm_rope(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                             int64_t seq_len, int n_heads_rot, int head_dim, const float* rope_table, int64_t table_len,
+                             const int32_t* positions, int dtype, void* stream) {
+    SSI_CHECK_ARG(A && B && C && rope_table && M >= 0 && N > 0 && K > 0 && seq_len > 0 && n_heads_rot > 0 && head_dim > 0);
+    SSI_CHECK_ARG((int64_t)n_heads_rot * head_dim <= N && (positions != nullptr || table_len >= seq_len));
+    if (M == 0) return SSI_OK;
+    int rc = SSI_OK;
+    if (dtype == SSI_BF16 && head_dim == 64 && g_impl != SSI_IMPL_GENERIC &&
+        ssi_gemm_rope_mfma(M, N, K, A, lda, B, ldb, C, ldc, rope_table, positions, seq_len, (int64_t)n_heads_rot * head_dim, stream, &rc))
+        return rc;
+    if ((rc = ssi_gemm(SSI_GEMM_NT, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 1.f, nullptr, 0, dtype, stream))) return rc;
+    return ssi_rope_inplace(C, ldc, M, seq_len, n_heads_rot, head_dim, rope_table, table_len, positions, 0, dtype, stream);
+}
+
 // ---- fused SwiGLU GEMMs (K7 of SURVEY.md §2.3: FeedForward w2(silu(w1 x) * w3 x) and its backward) -------------------------
 bool ssi_gemm_swiglu_supported(int64_t M, int64_t inter, int64_t K, const void* p0, const void* p1, const void* p2, const void* p3,
                                int64_t ld0, int64_t ld1, int64_t ld2, int64_t ld3);

@@ -140,13 +140,19 @@ __device__ int g_nt4_sched[16][16];
 // EPI: 0 plain epilogue; 1 SwiGLU forward (the 256 output columns of a tile are 128 gate + the matching 128 up columns of
 // W13; writes GU = [gate | up] and ACT = silu(gate) * up); 2 SwiGLU backward (C tile = d act, never stored: reads gate/up
 // from GU and writes d gate / d up into DGU).  Same rounding points as the separate swiglu kernels (bf16 GEMM result first).
-enum { EPI_PLAIN = 0, EPI_SWIGLU_FWD = 1, EPI_SWIGLU_BWD = 2 };
+enum { EPI_PLAIN = 0, EPI_SWIGLU_FWD = 1, EPI_SWIGLU_BWD = 2, EPI_ROPE = 3 };
 struct EpiArgs {
     bf16_t* out2;        // FWD: ACT [M, I]      BWD: DGU [M, 2I]
     int64_t ld_out2;
     const bf16_t* in2;   // BWD: GU [M, 2I]
     int64_t ld_in2;
     int64_t inter;       // I
+    // EPI_ROPE (QKV projection): interleaved RoPE on output columns [0, rot_cols) (the q and k heads, 64 wide), applied to the
+    // bf16-rounded GEMM result and rounded again = ssi_rope_inplace on the stored tensor
+    const float* rope = nullptr;    // [table_len, 32, 2] (cos, sin)
+    const int32_t* pos = nullptr;   // [M] positions, or NULL: position = row % seq
+    int64_t seq = 1;
+    int64_t rot_cols = 0;
 };
 
 template <bool A_COL, bool B_COL, bool SPLITK, int EPI = EPI_PLAIN>
@@ -835,6 +841,59 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
                     __builtin_amdgcn_sched_barrier(0);  // one duo at a time: bounded register pressure
                 }
             }
+        } else if constexpr (EPI == EPI_ROPE) {
+            const int64_t tile_off = row0 * ldc + (int64_t)tn * BN + wn * NT4_WN;
+            const __amdgpu_buffer_rsrc_t rsC = make_rsrc(C + tile_off);
+            const int voff = (int)((lane_row * ldc + lane_col) * 2);
+            auto soff = [&](int i, int hh, int jd) { return (int)(((i * 16 + hh * 8) * ldc + jd * 64) * 2); };
+            const bool rot = (int64_t)tn * BN < ea.rot_cols;  // tile-uniform: the v heads are not rotated (rot_cols is a multiple of 256)
+            // a lane's 8 columns start at a multiple of 8 inside a 64-wide head, the same one for every vector it stores: the
+            // (cos, sin) it needs depend on the row only.  Positions of its 16 rows first, then the table rows one m-tile ahead.
+            int prow[8][2];
+            f32x4 cs[2][2][2];  // [m-tile parity][row half][pairs 0-1 | pairs 2-3]
+            if (rot) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int64_t r = row0 + i * 16 + hh * 8 + lane_row;
+                        prow[i][hh] = ea.pos ? ea.pos[r] : (int)(r % ea.seq);
+                    }
+            }
+            auto ldcs = [&](int i) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const float* tb = ea.rope + (int64_t)prow[i][hh] * 64 + (lane_col & 63);
+                    cs[i & 1][hh][0] = *reinterpret_cast<const f32x4*>(tb);
+                    cs[i & 1][hh][1] = *reinterpret_cast<const f32x4*>(tb + 4);
+                }
+            };
+            auto rotate = [&](u32x4& o, const f32x4& c01, const f32x4& c23) {
+                bf16x8 v = __builtin_bit_cast(bf16x8, o);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x4& c = p < 2 ? c01 : c23;
+                    float o0, o1;
+                    ssi_rope_pair((float)v[2 * p], (float)v[2 * p + 1], c[(p & 1) * 2], c[(p & 1) * 2 + 1], o0, o1);
+                    v[2 * p] = (bf16_t)o0;
+                    v[2 * p + 1] = (bf16_t)o1;
+                }
+                o = __builtin_bit_cast(u32x4, v);
+            };
+            if (rot) ldcs(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (rot && i + 1 < 8) ldcs(i + 1);
+#pragma unroll
+                for (int jd = 0; jd < 2; ++jd) {
+                    u32x4 lo, hi;
+                    duo(i, jd * 4, scale_c, lo, hi);
+                    if (rot) { rotate(lo, cs[i & 1][0][0], cs[i & 1][0][1]); rotate(hi, cs[i & 1][1][0], cs[i & 1][1][1]); }
+                    __builtin_amdgcn_raw_buffer_store_b128(lo, rsC, voff, soff(i, 0, jd), NT4_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(hi, rsC, voff, soff(i, 1, jd), NT4_ST_AUX);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         } else if constexpr (EPI == EPI_SWIGLU_FWD) {
             // n-tiles 0..3 = gate columns c0 .. c0+63, n-tiles 4..7 = the matching up columns, c0 = tn*128 + wn*64:
             // GU = [gate | up], ACT = silu(gate).to(bf16) * up   (same rounding points as ssi_swiglu_fwd)
@@ -1096,6 +1155,18 @@ int ssi_gemm_mfma_bf16_splitk(int layout, int64_t M, int64_t N, int64_t K, const
     }
 #undef GO
     return SSI_ERR_ARG;
+}
+
+// QKV projection with the RoPE rotation of the q / k heads in the epilogue (head_dim 64, rot_cols % 256 == 0); false = not taken
+bool ssi_gemm_rope_mfma(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                        const float* rope, const int32_t* positions, int64_t seq, int64_t rot_cols, void* stream, int* rc) {
+    if (!nt4_ok(K) || !nt4_ld_ok(lda, ldb) || M % BM || N % BN || rot_cols % BN || rot_cols > N || lda % 8 || ldb % 8 || ldc % 8) return false;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return false;
+    EpiArgs ea{nullptr, 0, nullptr, 0, 0};
+    ea.rope = rope; ea.pos = positions; ea.seq = seq; ea.rot_cols = rot_cols;
+    *rc = launch_nt4<false, false, EPI_ROPE, 0>((int)(M / BM), (int)(N / BN), K, A, lda, B, ldb, C, ldc, nullptr, 1.f, nullptr,
+                                                (hipStream_t)stream, ea);
+    return true;
 }
 
 // ---- fused SwiGLU entries (MFMA path only; callers fall back to ssi_gemm + ssi_swiglu_* when this returns UNSUPPORTED) ----

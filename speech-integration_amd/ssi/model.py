@@ -347,8 +347,7 @@ class HipLlamaDecoder(nn.Module):
             rstd1 = A.get(f"rstd1.{sfx}", (T,), torch.float32)
             ops.rmsnorm_fwd(h, self._view(f"L{l}.sa_norm"), xn1, rstd1, self.norm_eps)
             qkv = A.get(f"qkv.{sfx}", (T, self.qkv_dim), dt)
-            ops.gemm(GEMM_NT, xn1, self._view(f"L{l}.wqkv"), qkv)
-            ops.rope_(qkv, S, H + KV, hd, self._rope, positions=pos)
+            ops.gemm_rope(xn1, self._view(f"L{l}.wqkv"), qkv, S, H + KV, hd, self._rope, positions=pos)  # RoPE in the GEMM epilogue
             att = A.get(f"att.{sfx}", (T, H * hd), dt)
             lse = A.get(f"lse.{sfx}", (B * H * S,), torch.float32)
             ops.attn_fwd(qkv, att, lse, B, S, H, KV, hd, ds, de)

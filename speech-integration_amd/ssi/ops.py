@@ -80,6 +80,20 @@ def rope_(x: Tensor, seq_len: int, n_heads_rot: int, head_dim: int, table: Tenso
           "ssi_rope_inplace")
 
 
+def gemm_rope(a: Tensor, b: Tensor, c: Tensor, seq_len: int, n_heads_rot: int, head_dim: int, table: Tensor,
+              positions: Tensor | None = None) -> None:
+    """c = a @ b^T, then ``rope_`` on the first ``n_heads_rot`` heads of every row of c (QKV projection + RoPE, one launch on the
+    MFMA path)."""
+    assert a.dim() == 2 and b.dim() == 2 and c.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and c.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and c.shape == (M, N) and a.dtype == b.dtype == c.dtype
+    assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[1] * 2 == head_dim
+    assert positions is None or (positions.dtype == torch.int32 and positions.numel() == M)
+    check(_lib.load().ssi_gemm_rope(M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(c), c.stride(0), seq_len, n_heads_rot, head_dim,
+                                    ptr(table), table.shape[0], ptr(positions), dtype_code(a.dtype), stream_ptr()), "ssi_gemm_rope")
+
+
 def _doc_ptrs(doc_start: Optional[Tensor], doc_end: Optional[Tensor], rows: int):
     if doc_start is None and doc_end is None:
         return None, None

@@ -705,3 +705,40 @@ def test_fused_swiglu_gemms_equal_the_unfused_kernels(ops):
         assert float(diff.max()) <= 2 ** -6 * float(dgu_ref.float().abs().max()) + 1e-3
     finally:
         ops.set_impl(prev)
+
+
+@pytest.mark.parametrize("explicit_positions", [False, True])
+def test_qkv_gemm_with_rope_in_the_epilogue_equals_gemm_then_rope(ops, explicit_positions):
+    """ssi_gemm_rope (persistent MFMA kernel, rotation in the epilogue) == ssi_gemm + ssi_rope_inplace bit for bit: the rotation
+    is applied to the bf16-rounded projection in both.  Three m-tiles x three n-tiles, the last n-tile (v heads) not rotated."""
+    from ssi import _lib
+    from ssi.model import llama3_rope_table
+    B, S, H, KV, hd, K = 3, 256, 6, 2, 64, 256       # N = (6 + 2*2) * 64 = 640 -> padded weight rows: use H + KV = 8 heads = 512 rotated
+    N = 768
+    table = llama3_rope_table(hd, 4096).to(DEV)
+    x = rnd(B * S, K, dtype=torch.bfloat16, seed=50).to(DEV)
+    w = rnd(N, K, dtype=torch.bfloat16, seed=51, scale=0.1).to(DEV)
+    pos = None
+    if explicit_positions:   # packed rows: positions restart inside a row and reach beyond S
+        pos = torch.cat([torch.arange(100), torch.arange(3000, 3000 + 412), torch.arange(B * S - 512)]).to(torch.int32).to(DEV)
+    ref = torch.empty(B * S, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(ops.GEMM_NT, x, w, ref)
+    plain = ref.clone()
+    ops.rope_(ref, S, 8, hd, table, positions=pos)
+    out = torch.full_like(ref, float("nan"))
+    ops.gemm_rope(x, w, out, S, 8, hd, table, positions=pos)
+    assert torch.equal(out, ref)
+    assert torch.equal(out[:, 512:], plain[:, 512:]) and not torch.equal(out[:, :512], plain[:, :512])
+    # shapes the fused kernel does not take (rotated width not a multiple of 256) and the generic implementation: two launches, same result
+    out2 = torch.full_like(ref, float("nan"))
+    ops.gemm_rope(x, w, out2, S, 7, hd, table, positions=pos)
+    ref2 = plain.clone()
+    ops.rope_(ref2, S, 7, hd, table, positions=pos)
+    assert torch.equal(out2, ref2)
+    prev = ops.set_impl(_lib.IMPL_GENERIC)
+    try:
+        out3 = torch.full_like(ref, float("nan"))
+        ops.gemm_rope(x, w, out3, S, 8, hd, table, positions=pos)
+    finally:
+        ops.set_impl(prev)
+    torch.testing.assert_close(out3.float(), ref.float(), rtol=2e-2, atol=2e-2)
