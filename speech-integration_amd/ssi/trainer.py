@@ -206,19 +206,23 @@ class Trainer:
         self.token_type_ranges = get_token_type_ranges(llama_config=self._llama_config)
 
     def _setup_data(self) -> None:
-        from .data import setup_synthetic_data
+        """``trainer.py:261-271``: SFT or CPT datasets by ``config_name``; ``dataset.source: synthetic`` (not in the reference)
+        selects the MLS-shaped generator that needs neither a tokenizer file nor a dataset."""
+        from .data import setup_sft_data, setup_synthetic_data, setup_text_completion_data
         for split in ("train", "dev"):
             node = self.cfg.data[split]
-            if node.dataset.get("source") != "synthetic":
-                raise NotImplementedError(
-                    f"data.{split}.dataset.source={node.dataset.get('source')!r}: the HF-datasets/tiktoken pipeline of the "
-                    "reference (ssi/data/*) is outside this build's hot-path scope; use source=synthetic (MLS-shaped DSU "
-                    "sequences) or inject dataloaders via Trainer.data_train / Trainer.data_dev")
-            loader, sampler = setup_synthetic_data(
-                n_samples=int(node.dataset.get("n_samples") or 1024), seq_len=int(self.cfg.tokenizer.max_seq_len),
-                batch_size=int(node.dataloader.batch_size), n_dsus=int(self.cfg.speech.n_dsus), world_size=self.world_size,
-                rank=self.rank, shuffle=bool(node.get("shuffle", False)), drop_last=bool(node.dataloader.get("drop_last", False)),
-                fixed_len=bool(node.dataset.get("fixed_len", True)), kind=str(self.cfg.config_name))
+            if node.dataset.get("source") == "synthetic":
+                loader, sampler = setup_synthetic_data(
+                    n_samples=int(node.dataset.get("n_samples") or 1024), seq_len=int(self.cfg.tokenizer.max_seq_len),
+                    batch_size=int(node.dataloader.batch_size), n_dsus=int(self.cfg.speech.n_dsus), world_size=self.world_size,
+                    rank=self.rank, shuffle=bool(node.get("shuffle", False)), drop_last=bool(node.dataloader.get("drop_last", False)),
+                    fixed_len=bool(node.dataset.get("fixed_len", True)), kind=str(self.cfg.config_name))
+            elif self.cfg.config_name == "sft":
+                loader, sampler = setup_sft_data(cfg_dataset=node, model_tokenizer=self.tokenizer)
+            elif self.cfg.config_name == "cpt":
+                loader, sampler = setup_text_completion_data(node, self.tokenizer)
+            else:
+                raise NotImplementedError(f"Unsupported config_name: {self.cfg.config_name}")
             if split == "train":
                 self.data_train, self.sampler_train = loader, sampler
             else:

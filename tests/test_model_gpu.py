@@ -430,3 +430,67 @@ def test_full_size_step_properties():
     with torch.inference_mode():
         le = compute_loss(b1, model, loss_fn).item()
     assert abs(le - l1) <= 1e-6 * abs(l1)                                            # (4)
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_trainer_on_sft_samples_from_a_json_file_and_a_tokenizer_file(tmp_path, monkeypatch, packed):
+    """The data front end feeding the step: speech units + transcripts in a local json file, a (toy) extended tokenizer.model,
+    ``setup_sft_data`` -> padded or packed batches -> Trainer.train(); per-step losses against the CPU step oracle on the same batches."""
+    import json
+    from oracle import step_oracle
+    from oracle.llama_oracle import OracleCEWithChunkedOutputLoss, OracleLlama
+    from ssi.config import compose
+    from ssi.lr_schedule import get_cosine_schedule_with_warmup
+    from ssi.train_utils import resolve_n_dsus
+    from ssi.trainer import Trainer
+    from conftest import PKG
+    from test_data_pipeline import N_TXT, N_UNITS, ROWS, toy_ranks
+    from ssi.tokenizer import dump_tiktoken_bpe
+    monkeypatch.setenv("HF_DATASETS_OFFLINE", "1")
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf"))
+    dump_tiktoken_bpe(toy_ranks(), tmp_path / "tokenizer.model")
+    (tmp_path / "train.jsonl").write_text("\n".join(json.dumps(r) for r in ROWS))
+    cfg = compose(os.path.join(PKG, "conf"), "sft", [
+        "data=sft/mls-speechtokenizer-rvq_0", "dtype=fp32", "max_steps=2", "gradient_accumulation_steps=1", "tokenizer.max_seq_len=128",
+        "eval_steps=2", "save_steps=100", "lr_scheduler.num_warmup_steps=1", "optimizer.lr=1e-3", f"output_dir={tmp_path}",
+        f"checkpointer.output_dir={tmp_path}/ckpt", f"checkpointer.checkpoint_dir={tmp_path}/none", "data.train.shuffle=false",
+        f"tokenizer.path={tmp_path}/tokenizer.model", "tokenizer.verbose=false",
+        "data.train.dataset.source=json", "data.dev.dataset.source=json", "data.train.dataset.n_samples=null", "data.dev.dataset.n_samples=4",
+        "data.dev.dataset.split=train", f"data.train.packed={'true' if packed else 'false'}", "data.train.dataloader.batch_size=2",
+    ])
+    cfg.data.train.dataset.data_files = str(tmp_path / "train.jsonl")
+    cfg.data.dev.dataset.data_files = str(tmp_path / "train.jsonl")
+    cfg.model_overrides = {"num_layers": 2, "num_heads": 4, "num_kv_heads": 2, "embed_dim": 64, "intermediate_dim": 128,
+                           "max_seq_len": 256, "_base_vocab_size_txt": N_TXT, "_n_special_txt": 256}
+    cfg.speech.n_dsus = N_UNITS
+    cfg.data.n_dsus = N_UNITS
+    resolve_n_dsus(cfg)
+    t = Trainer(cfg)
+    t.setup()
+    assert t.tokenizer.vocab_size == t._llama_config.vocab_size == N_TXT + N_UNITS + 2 + 256
+    assert type(t.data_train.dataset).__name__ == ("PackedDataset" if packed else "SFTDataset")
+    t._loss_log = []
+    sd0 = {k: v.detach().float().cpu().clone() for k, v in t.model.state_dict().items()}
+    batches = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()} for b in itertools_islice(t.data_train, 2)]
+    assert ("input_pos" in batches[0]) == packed and batches[0]["tokens"].shape[0] == 2
+    t.train()
+    assert t.global_step == 2 and len(t._loss_log) == 2
+    ref = OracleLlama(**t._llama_config.parameters, rope_cache_len=256)
+    ref.load_state_dict(sd0)
+    ref.set_num_output_chunks(8)
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    sched = get_cosine_schedule_with_warmup(opt, num_warmup_steps=1, num_training_steps=2, num_cycles=0.5)
+    if packed:
+        from ssi.data import packed_block_causal_mask
+        batches = [{**b, "mask": packed_block_causal_mask(b["seq_lens"])} for b in batches]
+    losses = step_oracle.run_steps(ref, OracleCEWithChunkedOutputLoss(), [batches[0:1], batches[1:2]], opt, sched)
+    print("gpu", t._loss_log, "cpu", losses)
+    for a, b in zip(t._loss_log, losses):
+        assert abs(a - b) <= 2e-5 * abs(b)
+    # the unit and modality counters see the real ids (deduplicated unit runs between the two modality tokens)
+    counts = {}
+    for b in batches:
+        for k, v in step_oracle.count_token_types(b["tokens"], t.token_type_ranges, t.tokenizer.pad_id).items():
+            counts[k] = counts.get(k, 0) + v
+    assert dict(t.token_type_counts_total) == counts and counts["dsu"] > 0 and counts["modality"] >= 2 * 4
+    t.cleanup()
