@@ -100,6 +100,16 @@ template <typename T> __device__ __forceinline__ void store16(T* p, const Vec16<
     *reinterpret_cast<decltype(r.v)*>(p) = r.v;
 }
 
+// streaming forms (touched once per launch: keep them out of the way of what the caches could hold)
+template <typename T> __device__ __forceinline__ Vec16<T> load16_nt(const T* p) {
+    Vec16<T> r;
+    r.v = __builtin_nontemporal_load(reinterpret_cast<const decltype(r.v)*>(p));
+    return r;
+}
+template <typename T> __device__ __forceinline__ void store16_nt(T* p, const Vec16<T>& r) {
+    __builtin_nontemporal_store(r.v, reinterpret_cast<decltype(r.v)*>(p));
+}
+
 // ---- reductions ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -284,9 +284,9 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ d
     }
 }
 
-static inline unsigned stream_grid(int64_t work_items) {
+static inline unsigned stream_grid(int64_t work_items, int64_t cap = 8192) {
     int64_t b = ssi_cdiv(work_items, 256);
-    return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+    return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 extern "C" int ssi_swiglu_fwd(const void* gu, void* act, int64_t rows, int64_t inter, int dtype, void* stream) {
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* __restrict__ p, T* __rest
     const float gs = grad_scale_dev ? *grad_scale_dev : 1.f;
     const int64_t nvec = n / N;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-        Vec16<T> pp = load16(p + i * N), gg = load16(g + i * N), mm = load16(m + i * N), vv = load16(v + i * N);
+        Vec16<T> pp = load16_nt(p + i * N), gg = load16_nt(g + i * N), mm = load16_nt(m + i * N), vv = load16_nt(v + i * N);
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const float gr = gg.get(k) * gs;
@@ -456,8 +456,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* __restrict__ p, T* __rest
             pp.set(k, pf); mm.set(k, mf); vv.set(k, vf);
             if (zero_grad) gg.set(k, 0.f);
         }
-        store16(p + i * N, pp); store16(m + i * N, mm); store16(v + i * N, vv);
-        if (zero_grad) store16(g + i * N, gg);
+        store16_nt(p + i * N, pp); store16_nt(m + i * N, mm); store16_nt(v + i * N, vv);
+        if (zero_grad) store16_nt(g + i * N, gg);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n - nvec * N)) {
         const int64_t i = nvec * N + threadIdx.x;
@@ -482,7 +482,8 @@ extern "C" int ssi_adamw_step(void* param, void* grad, void* exp_avg, void* exp_
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    SSI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(adamw_kernel<T>, dim3(stream_grid(n / Vec16<T>::N + 1)), dim3(256), 0,
+    // 20 GB touched once: non-temporal accesses and many short blocks measured 6 % faster than 8192 long-lived ones (tools/lab)
+    SSI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(adamw_kernel<T>, dim3(stream_grid(n / Vec16<T>::N + 1, 32768)), dim3(256), 0,
                                                  (hipStream_t)stream, (T*)param, (T*)grad, (T*)exp_avg, (T*)exp_avg_sq, n,
                                                  lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
                                                  grad_scale_dev, zero_grad));
