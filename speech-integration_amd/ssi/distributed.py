@@ -54,6 +54,8 @@ class GradSync:
         self.flat_grad, self.buckets, self.group = flat_grad, list(buckets), group
         self._pending: list = []
         self._done: set[str] = set()
+        self._deferred = None          # (work, (lo, hi)) of the bucket finish(defer_last=True) left in flight
+        self._last_range = (0, 0)
         self._comm_stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         self.bytes_reduced = 0
         if flat_grad.is_cuda and self.enabled:
@@ -70,6 +72,7 @@ class GradSync:
         if not self.enabled or name in self._done or hi <= lo:
             return
         self._done.add(name)
+        self._last_range = (lo, hi)
         buf = self.flat_grad[lo:hi]
         self.bytes_reduced += buf.numel() * buf.element_size()
         if self._comm_stream is not None:
@@ -82,16 +85,33 @@ class GradSync:
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append(work)
 
-    def finish(self) -> None:
+    def finish(self, defer_last: bool = False) -> None:
+        """Reduce whatever was not announced and make the compute stream wait for the reductions.  With ``defer_last`` the
+        wait for the bucket issued last (the tied embedding: 546 MB that backward finishes at its very end, so nothing is
+        left to hide it behind) is left to ``finish_deferred()``: the optimizer updates every other parameter first
+        (``HipAdamW.step``) while that reduction is still on the links.  Only for callers that do not read the whole
+        gradient in between (no global-norm clipping)."""
+        self._deferred = None
         if self.enabled:
             for name, lo, hi in self.buckets:
                 self.bucket_ready(name, lo, hi)
+            if defer_last and len(self._pending) > 1:
+                self._deferred = (self._pending.pop(), self._last_range)
             for work in self._pending:
                 work.wait()
             if self._comm_stream is not None:
                 torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._comm_stream)
         self._pending.clear()
         self._done.clear()
+
+    def deferred_range(self) -> Optional[tuple[int, int]]:
+        """``[lo, hi)`` of the flat gradient that is not final until ``finish_deferred()``; None when nothing is pending."""
+        return self._deferred[1] if self._deferred is not None else None
+
+    def finish_deferred(self) -> None:
+        if self._deferred is not None:
+            self._deferred[0].wait()
+            self._deferred = None
 
     @classmethod
     def for_module(cls, module: torch.nn.Module, group=None) -> "ModuleGradSync":
@@ -111,7 +131,7 @@ class ModuleGradSync(GradSync):
     def bucket_ready(self, name: str, lo: int, hi: int) -> None:  # no early buckets for foreign modules
         return
 
-    def finish(self) -> None:
+    def finish(self, defer_last: bool = False) -> None:
         if not self.enabled:
             return
         grads = [p.grad for p in self.params if p.grad is not None]

@@ -54,9 +54,24 @@ class HipAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]
         m = self.model
         self._step_count += 1
-        ops.adamw_step(m._flat, m._flat_grad, self._exp_avg, self._exp_avg_sq, lr=float(g["lr"]), beta1=g["betas"][0],
-                       beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], step=self._step_count,
-                       grad_scale_dev=m.pending_grad_scale, zero_grad=True)
+
+        def update(lo: int, hi: int) -> None:
+            if hi > lo:
+                ops.adamw_step(m._flat[lo:hi], m._flat_grad[lo:hi], self._exp_avg[lo:hi], self._exp_avg_sq[lo:hi], lr=float(g["lr"]),
+                               beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
+                               step=self._step_count, grad_scale_dev=m.pending_grad_scale, zero_grad=True)
+
+        sync = getattr(m, "grad_sync", None)
+        tail = sync.deferred_range() if sync is not None and hasattr(sync, "deferred_range") else None
+        n = m._flat.numel()
+        if tail is None:
+            update(0, n)
+        else:  # data parallel: everything but the bucket still being reduced first, that bucket once it has arrived
+            lo, hi = tail
+            update(0, lo)
+            update(hi, n)
+            sync.finish_deferred()
+            update(lo, hi)
         m.pending_grad_scale = None
         m._grads_dirty = False
         m._hip_epoch += 1  # weights changed behind torch's version counter
@@ -67,6 +82,9 @@ class HipAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         # the fused step already zeroed the buffer when it ran; zero again only if gradients are pending
+        sync = getattr(self.model, "grad_sync", None)
+        if sync is not None and hasattr(sync, "finish_deferred"):
+            sync.finish_deferred()  # a step that was skipped must not zero under a reduction in flight
         self.model.zero_grad(set_to_none=set_to_none)
 
     def state_dict(self):
@@ -134,6 +152,9 @@ def clip_grad_norm_(model, max_norm: float) -> Tensor:
     Returns the total norm (device tensor, of the scaled gradients)."""
     if not hasattr(model, "_flat_grad"):
         return torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=float(max_norm))
+    sync = getattr(model, "grad_sync", None)
+    if sync is not None and hasattr(sync, "finish_deferred"):
+        sync.finish_deferred()  # the norm reads every gradient
     out = torch.empty(1, dtype=torch.float32, device=model._flat_grad.device)
     ops.sumsq(model._flat_grad, out)
     scale = model.pending_grad_scale if model.pending_grad_scale is not None else torch.ones_like(out)

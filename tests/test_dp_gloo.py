@@ -102,3 +102,50 @@ def test_two_rank_step_equals_single_process_step(tmp_path):
     assert r0["consumed"] == 2 * 2 * 2  # ga * batch * world
     total = {k: r0["counts"][k] + r1["counts"][k] for k in r0["counts"]}
     assert total == dict(t.token_type_counts_total)
+
+
+def _bucket_worker(rank, world_size, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from ssi.distributed import GradSync
+        flat = torch.arange(12, dtype=torch.float32) * (rank + 1)            # rank 0: 0..11, rank 1: 0..22 step 2
+        buckets = [("norm", 10, 12), ("L0", 4, 10), ("emb", 0, 4)]           # the order backward finishes them
+        sync = GradSync(flat, buckets)
+        log = {}
+        sync.bucket_ready(*buckets[0])                                       # announced during backward
+        sync.bucket_ready(*buckets[0])                                       # twice: reduced once
+        sync.finish(defer_last=True)                                         # issues L0 and emb, leaves emb in flight
+        log["deferred"] = sync.deferred_range()
+        log["after_finish"] = flat[4:].clone()
+        sync.finish_deferred()
+        log["after_deferred"] = flat.clone()
+        log["bytes"] = sync.bytes_reduced
+        assert sync.deferred_range() is None
+        # second window, nothing deferred: everything final after finish()
+        flat.copy_(torch.ones(12) * (rank + 1))
+        sync.finish()
+        log["second"] = flat.clone()
+        torch.save(log, os.path.join(out_dir, f"b{rank}.pt"))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_exchange_with_the_embedding_bucket_deferred(tmp_path):
+    """GradSync on a flat gradient buffer: per-bucket SUM all-reduce, each bucket once; ``finish(defer_last=True)`` leaves the bucket
+    issued last (the tied embedding) to ``finish_deferred()`` so that the optimizer can update the other parameters meanwhile."""
+    port = _free_port()
+    mp.spawn(_bucket_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    want = torch.arange(12, dtype=torch.float32) * 3
+    for r in range(2):
+        log = torch.load(tmp_path / f"b{r}.pt", weights_only=False)
+        assert log["deferred"] == (0, 4)
+        assert torch.equal(log["after_finish"], want[4:])          # norm and L0 are final after finish()
+        assert torch.equal(log["after_deferred"], want)            # the embedding bucket after finish_deferred()
+        assert log["bytes"] == 12 * 4
+        assert torch.equal(log["second"], torch.full((12,), 3.0))
