@@ -277,8 +277,8 @@ def main() -> int:
         host = torch.cat((counts.double(), loss_batch.detach().double().reshape(1))).tolist()  # the step's one D2H sync
         n_tok, loss_run = int(host[-2]), host[-1]
         if sync is not None:
+            n_tok, loss_run = (lambda v: (int(round(v[0])), v[1]))(all_reduce_scalars([n_tok, loss_run], device, group=sync.scalar_group))
             sync.finish(defer_last=not os.environ.get("SSI_BENCH_NO_DEFER"))
-            n_tok, loss_run = (lambda v: (int(round(v[0])), v[1]))(all_reduce_scalars([n_tok, loss_run], device))
         scale_grads(model, torch.tensor(1.0 / n_tok))
         opt.step()
         opt.zero_grad(set_to_none=True)

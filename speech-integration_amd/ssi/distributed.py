@@ -58,6 +58,9 @@ class GradSync:
         self._last_range = (0, 0)
         self._comm_stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         self.bytes_reduced = 0
+        # token counts and the running loss travel on a communicator of their own: on the gradients' one they would queue behind
+        # every bucket already issued (a communicator runs its collectives in issue order), the deferred embedding bucket included
+        self.scalar_group = dist.new_group() if self.enabled else None
         if flat_grad.is_cuda and self.enabled:
             # RCCL's kernels hold CUs for the length of a reduction while the backward GEMMs run: a persistent GEMM with a fixed
             # tile-to-workgroup map would wait a whole round for the workgroups that could not start (include/ssi_hip.h)

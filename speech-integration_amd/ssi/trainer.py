@@ -351,9 +351,9 @@ class Trainer:
     def _optimizer_step(self, epoch: int, iter_idx: int) -> None:
         """Accumulation boundary (``trainer.py:397-424``): [all-reduce] -> scale -> clip -> AdamW -> LR -> counters."""
         if self.grad_sync is not None:
+            self.num_tokens_step, self.loss_running = (lambda v: (int(round(v[0])), float(v[1])))(
+                all_reduce_scalars([self.num_tokens_step, self.loss_running], self.device, group=self.grad_sync.scalar_group))
             self.grad_sync.finish(defer_last=self.cfg.clip_grad_norm is None)  # the embedding bucket lands under the AdamW of the rest
-            self.num_tokens_step, self.loss_running = (
-                lambda v: (int(round(v[0])), float(v[1])))(all_reduce_scalars([self.num_tokens_step, self.loss_running], self.device))
         if self.num_tokens_step == 0:
             LOGGER.warning("No non-ignored tokens in accumulation window; skipping optimizer step.")
             self.optimizer.zero_grad(set_to_none=True)
