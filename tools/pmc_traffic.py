@@ -16,5 +16,8 @@ write, n2 = avg(sys.argv[2], "WRITE_SIZE", sys.argv[3])
 out = {"kernel": sys.argv[3], "launches_sampled": [n1, n2], "FETCH_SIZE_KB_avg": fetch, "WRITE_SIZE_KB_avg": write,
        "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
        "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KB units); FETCH_SIZE doubled per the gfx950 correction"}
+out["bench_kernel"] = sys.argv[3].replace(", ", ",")   # the symbol as bench.py's roofline names it
+if len(sys.argv) > 5:
+    out["command"] = sys.argv[5]
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(out))
