@@ -42,6 +42,23 @@ __device__ __forceinline__ bf16x4 unrope4(bf16x4 v, const float* __restrict__ tb
     return o;
 }
 
+// Workgroup -> (rank of the block inside its (batch, kv head) pair, pair).  Workgroups go to the 8 XCDs round-robin by
+// blockIdx, and under the causal mask a block's work is proportional to its rank, so a plain "block = blockIdx % n" map hands
+// XCD x only the blocks of rank x, x + 8, ...: 2.4x the work for XCD 0 as for XCD 7 at 16 blocks per pair, and the kernel lasts
+// as long as XCD 0.  Here every XCD gets whole pairs (n_pairs / 8 of them: equal work, and a pair's K / V or Q / dO stay in one
+// L2) and meets their blocks in rank order — with `rank` counting from the heaviest block, longest first across its pairs.
+__device__ __forceinline__ void block_to_work(int n_blocks, int n_pairs, int& rank, int& pair) {
+    const int i = (int)blockIdx.x;
+    if (n_pairs % 8 == 0) {
+        const int ppx = n_pairs / 8, xcd = i & 7, j = i >> 3;
+        rank = j / ppx;
+        pair = xcd * ppx + j % ppx;
+    } else {
+        rank = i % n_blocks;
+        pair = i / n_blocks;
+    }
+}
+
 __device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int HD = 64;
@@ -140,9 +157,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const int rep = H / KV, qpw = 4 / rep;
     const int nqb = S / (32 * qpw);
     // heavy q-blocks first
-    const int qgrp = nqb - 1 - (int)(blockIdx.x % nqb);
-    const int kvh = (int)(blockIdx.x / nqb) % KV;
-    const int b = (int)(blockIdx.x / nqb) / KV;
+    int rank_, pair_;
+    block_to_work(nqb, (int)(gridDim.x / nqb), rank_, pair_);
+    const int qgrp = nqb - 1 - rank_;
+    const int kvh = pair_ % KV;
+    const int b = pair_ / KV;
     const int head = kvh * rep + wave % rep;
     const int q0 = (qgrp * qpw + wave / rep) * 32;
     const int q_last_wg = (qgrp * qpw + qpw - 1) * 32 + 31;
@@ -273,9 +292,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep = H / KV, qpw = 4 / rep;
     const int nqb = S / (32 * qpw);
-    const int qgrp = nqb - 1 - (int)(blockIdx.x % nqb);
-    const int kvh = (int)(blockIdx.x / nqb) % KV;
-    const int b = (int)(blockIdx.x / nqb) / KV;
+    int rank_, pair_;
+    block_to_work(nqb, (int)(gridDim.x / nqb), rank_, pair_);
+    const int qgrp = nqb - 1 - rank_;
+    const int kvh = pair_ % KV;
+    const int b = pair_ / KV;
     const int head = kvh * rep + wave % rep;
     const int q0 = (qgrp * qpw + wave / rep) * 32;
     const int nt = ((qgrp * qpw + qpw - 1) * 32 + 31) / 64 + 1;
@@ -410,9 +431,10 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep = H / KV;
     const int ngrp = S / 128;
-    const int kgrp = (int)(blockIdx.x % ngrp);  // low key groups (most work) are dispatched first
-    const int kvh = (int)(blockIdx.x / ngrp) % KV;
-    const int b = (int)(blockIdx.x / ngrp) / KV;
+    int kgrp, pair_;  // low key groups (most work) are dispatched first
+    block_to_work(ngrp, (int)(gridDim.x / ngrp), kgrp, pair_);
+    const int kvh = pair_ % KV;
+    const int b = pair_ / KV;
     const int h = lane >> 5;
     const int64_t row0 = (int64_t)b * S;
     const int64_t ldo = (int64_t)H * HD;
