@@ -6,6 +6,69 @@
 // =====================================================================================================================
 // K2 RMSNorm forward: one wave per row (torchtune.modules.RMSNorm.forward)
 // =====================================================================================================================
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ scale,
+                                                          T* __restrict__ y, float* __restrict__ rstd_out,
+                                                          int64_t rows, int dim, float eps) {
+    constexpr int N = Vec16<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int nvec = dim / N;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), wave_stride = (int64_t)gridDim.x * 4;
+    // each row is read once, into registers; the next row of the wave is in flight while this one is reduced and written
+    Vec16<T> w[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int v = lane + k * 64;
+        if (v < nvec) w[k] = load16(scale + v * N);
+    }
+    auto fetch = [&](int64_t row, Vec16<T>* a) {
+        if (row >= rows) return;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int v = lane + k * 64;
+            if (v < nvec) a[k] = load16(x + row * dim + v * N);
+        }
+    };
+    auto finish = [&](int64_t row, const Vec16<T>* a) {
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int v = lane + k * 64;
+            if (v < nvec) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) { float f = a[k].get(i); ss += f * f; }
+            }
+        }
+        ss = wave_sum(ss);
+        const float rstd = rsqrtf(ss / (float)dim + eps);
+        if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int v = lane + k * 64;
+            if (v < nvec) {
+                Vec16<T> o;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    // (x32 * rstd).type_as(x) * scale : round to storage type before the scale multiply
+                    float xn = to_f32<T>(from_f32<T>(a[k].get(i) * rstd));
+                    o.set(i, xn * w[k].get(i));
+                }
+                store16(y + row * dim + v * N, o);
+            }
+        }
+    };
+    Vec16<T> a0[MAXV], a1[MAXV];
+    fetch(wave_global, a0);
+    for (int64_t row = wave_global; row < rows; row += 2 * wave_stride) {
+        fetch(row + wave_stride, a1);
+        finish(row, a0);
+        if (row + wave_stride >= rows) break;
+        fetch(row + 2 * wave_stride, a0);
+        finish(row + wave_stride, a1);
+    }
+}
+
+// =====================================================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ scale,
                                                           T* __restrict__ y, float* __restrict__ rstd_out,
@@ -56,21 +119,41 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
         for (int i = 0; i < N; ++i) dw[k][i] = 0.f;
 
     const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
-    for (int64_t row = wave_global; row < rows; row += wave_stride) {
-        const T* xr = x + row * dim;
-        const T* dyr = dy + row * dim;
-        const float rs = rstd[row];
+    // A wave walks rows/waves rows one after the other (the dscale sums stay in its registers), so it alone would pay the whole
+    // memory latency twice per row: each row is read ONCE, into registers, and the next row's loads are in flight while this
+    // one is reduced and written (two register sets, alternating).
+    struct RowRegs { Vec16<T> a[MAXV], g[MAXV], r[MAXV]; float rs; };
+    Vec16<T> w[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int v = lane + k * 64;
+        if (v < nvec) w[k] = load16(scale + v * N);
+    }
+    auto fetch = [&](int64_t row, RowRegs& q) {
+        if (row >= rows) return;
+        q.rs = rstd[row];
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int v = lane + k * 64;
+            if (v < nvec) {
+                q.a[k] = load16(x + row * dim + v * N);
+                q.g[k] = load16(dy + row * dim + v * N);
+                if (dres) q.r[k] = load16(dres + row * dim + v * N);
+            }
+        }
+    };
+    auto finish = [&](int64_t row, const RowRegs& q) {
+        const float rs = q.rs;
         float c = 0.f;
 #pragma unroll
         for (int k = 0; k < MAXV; ++k) {
             const int v = lane + k * 64;
             if (v < nvec) {
-                Vec16<T> a = load16(xr + v * N), g = load16(dyr + v * N), w = load16(scale + v * N);
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    const float xhat = a.get(i) * rs;
-                    c += g.get(i) * w.get(i) * xhat;
-                    dw[k][i] += g.get(i) * xhat;
+                    const float xhat = q.a[k].get(i) * rs;
+                    c += q.g[k].get(i) * w[k].get(i) * xhat;
+                    dw[k][i] += q.g[k].get(i) * xhat;
                 }
             }
         }
@@ -79,19 +162,26 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
         for (int k = 0; k < MAXV; ++k) {
             const int v = lane + k * 64;
             if (v < nvec) {
-                Vec16<T> a = load16(xr + v * N), g = load16(dyr + v * N), w = load16(scale + v * N), o;
-                Vec16<T> r;
-                if (dres) r = load16(dres + row * dim + v * N);
+                Vec16<T> o;
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    const float xhat = a.get(i) * rs;
-                    float d = rs * (g.get(i) * w.get(i) - xhat * c);
-                    if (dres) d += r.get(i);
+                    const float xhat = q.a[k].get(i) * rs;
+                    float d = rs * (q.g[k].get(i) * w[k].get(i) - xhat * c);
+                    if (dres) d += q.r[k].get(i);
                     o.set(i, d);
                 }
                 store16(dx + row * dim + v * N, o);
             }
         }
+    };
+    RowRegs q0, q1;
+    fetch(wave_global, q0);
+    for (int64_t row = wave_global; row < rows; row += 2 * wave_stride) {
+        fetch(row + wave_stride, q1);
+        finish(row, q0);
+        if (row + wave_stride >= rows) break;
+        fetch(row + 2 * wave_stride, q0);
+        finish(row + wave_stride, q1);
     }
     // block reduce of dscale partials
 #pragma unroll
@@ -137,8 +227,10 @@ __global__ __launch_bounds__(1024) void colsum_accum_kernel(const float* __restr
 }
 
 static inline int rmsnorm_bwd_blocks(int64_t rows) {
+    // one 4-wave block per CU: with the row prefetch a wave hides its own latency, and fewer blocks mean fewer partial rows for the
+    // column sum (measured at 16384 x 2048 bf16: 256 blocks 45.7 us, 512 50.3, 1024 60.3; before the prefetch 512 was best at 54.4)
     int64_t b = ssi_cdiv(rows, 4);
-    return (int)(b < 512 ? b : 512);
+    return (int)(b < 256 ? b : 256);
 }
 
 extern "C" int64_t ssi_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t dim) {
@@ -149,9 +241,17 @@ extern "C" int ssi_rmsnorm_fwd(const void* x, const void* scale, void* y, float*
                                float eps, int dtype, void* stream) {
     SSI_CHECK_ARG(x && scale && y && rows >= 0 && dim > 0 && dim % 8 == 0);
     if (rows == 0) return SSI_OK;
-    SSI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(rmsnorm_fwd_kernel<T>, dim3((unsigned)ssi_cdiv(rows, 4)), dim3(256), 0,
-                                                 (hipStream_t)stream, (const T*)x, (const T*)scale, (T*)y, rstd, rows,
-                                                 (int)dim, eps));
+    const int64_t nb = ssi_cdiv(rows, 4) < 1024 ? ssi_cdiv(rows, 4) : 1024;  // 16384 x 2048 bf16: 1024 blocks 20.7 us, 256 23.7, 4096 21.2
+    const int64_t vec_per_lane = ssi_cdiv(dim / (dtype == SSI_BF16 ? 8 : 4), 64);
+    if (vec_per_lane > 8) { ssi_set_error("rmsnorm_fwd: dim %d too large", (int)dim); return SSI_ERR_UNSUPPORTED; }
+#define SSI_RMS_FWD(MV)                                                                                                              \
+    SSI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((rmsnorm_fwd_kernel<T, MV>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, \
+                                                 (const T*)x, (const T*)scale, (T*)y, rstd, rows, (int)dim, eps))
+    if (vec_per_lane <= 1) { SSI_RMS_FWD(1); }
+    else if (vec_per_lane <= 2) { SSI_RMS_FWD(2); }
+    else if (vec_per_lane <= 4) { SSI_RMS_FWD(4); }
+    else { SSI_RMS_FWD(8); }
+#undef SSI_RMS_FWD
     SSI_LAUNCH_CHECK();
     return SSI_OK;
 }
