@@ -264,6 +264,9 @@ def main() -> int:
     else:
         batches = [{k: v.to(device) for k, v in synthetic_batch(args.batch, args.seq, args.n_dsus, rank=rank, index=i % 4,
                                                                 fixed_len=not args.padded).items()} for i in range(min(n_total, 4))]
+    if os.environ.get("SSI_BENCH_TILE_ORDER"):  # diagnostic: price of the data-parallel tile order on one GPU ("dynamic" | "static")
+        from ssi import ops as _ops
+        _ops.set_gemm_tile_order(dynamic=os.environ["SSI_BENCH_TILE_ORDER"] == "dynamic")
     timer = GemmTimer()
     if not args.no_gemm_timing and rank == 0:
         timer.install()
