@@ -69,26 +69,70 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
     for (int k = 0; k < MAXV; ++k)
 #pragma unroll
         for (int i = 0; i < N; ++i) acc[k][i] = 0.f;
+    // A frequent token (hundreds of occurrences spread over the sequence) makes this wave the one the launch waits for, and a
+    // scan that fetched one 64-position chunk of ids, then the matching row, then the next chunk ... was a chain of dependent
+    // memory round trips (0.5 ms at 16 384 tokens).  So: the ids of SCAN chunks are requested together, the positions that match
+    // are listed in LDS in increasing order, and their rows are requested ROWS at a time and added in list order.
+    constexpr int SCAN = 8, ROWS = 8;
+    __shared__ int hits_lds[4][64 * SCAN];
+    int* hits = hits_lds[threadIdx.x >> 6];
     int found = 0;
-    for (int64_t base = (t0 / 64) * 64; base < n_tok && found < need; base += 64) {
-        const int64_t idx = base + lane;
-        const bool hit = idx < n_tok && idx >= t0 && tokens[idx] == tok;
-        unsigned long long mask = __ballot(hit);
-        while (mask) {
-            const int b = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const T* src = dout + (base + b) * dim;
+    // every load below is unconditional on a clamped address and its result is masked afterwards: behind a branch hipcc waits for
+    // each guarded load before it issues the next, which is the chain all over again
+    for (int64_t base0 = (t0 / 64) * 64; base0 < n_tok && found < need; base0 += 64 * SCAN) {
+        int64_t tk[SCAN];
+#pragma unroll
+        for (int u = 0; u < SCAN; ++u) {
+            const int64_t idx = base0 + 64 * u + lane;
+            tk[u] = tokens[idx < n_tok ? idx : n_tok - 1];
+        }
+        int n = 0;
+#pragma unroll
+        for (int u = 0; u < SCAN; ++u) {
+            const int64_t idx = base0 + 64 * u + lane;
+            const bool hit = idx < n_tok && idx >= t0 && tk[u] == tok;
+            const unsigned long long mask = __ballot(hit);
+            if (hit) hits[n + __popcll(mask & ((1ull << lane) - 1ull))] = (int)(idx - base0);
+            n += __popcll(mask);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the list is written before it is read back (same wave, no barrier needed)
+        if (n == 1) {  // the common case (a token seen once in these 512 positions): one row, no padding requests
+            const T* src = dout + (base0 + hits[0]) * dim;
 #pragma unroll
             for (int k = 0; k < MAXV; ++k) {
                 const int v = lane + k * 64;
-                if (v < nvec) {
-                    Vec16<T> a = load16(src + v * N);
+                const Vec16<T> r = load16(src + (v < nvec ? v : nvec - 1) * N);
 #pragma unroll
-                    for (int i = 0; i < N; ++i) acc[k][i] += a.get(i);
+                for (int i = 0; i < N; ++i) acc[k][i] += v < nvec ? r.get(i) : 0.f;
+            }
+        } else
+        for (int h0 = 0; h0 < n; h0 += ROWS) {
+            int pos[ROWS];
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) pos[u] = hits[h0 + u < n ? h0 + u : n - 1];
+            Vec16<T> a[ROWS][MAXV];
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                const T* src = dout + (base0 + pos[u]) * dim;
+#pragma unroll
+                for (int k = 0; k < MAXV; ++k) {
+                    const int v = lane + k * 64;
+                    a[u][k] = load16(src + (v < nvec ? v : nvec - 1) * N);
                 }
             }
-            ++found;
+            __builtin_amdgcn_sched_barrier(0);  // all ROWS x MAXV requests leave before the first is waited for (the scheduler sinks them otherwise)
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                const bool row_ok = h0 + u < n;  // wave-uniform
+#pragma unroll
+                for (int k = 0; k < MAXV; ++k) {
+                    const bool ok = row_ok && lane + k * 64 < nvec;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) acc[k][i] += ok ? a[u][k].get(i) : 0.f;
+                }
+            }
         }
+        found += n;
     }
     T* dst = dtable + tok * dim;
 #pragma unroll
