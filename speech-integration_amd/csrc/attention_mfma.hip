@@ -547,14 +547,23 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
 #pragma unroll
     for (int i = 0; i < RING - 2; ++i)
         if (i < n_steps) issue(i);
+    static_assert(RING % 2 == 0 && RING >= 4 && RING <= 10, "the barrier cadence (one per two steps) needs an even ring");
     for (int step = 0; step < n_steps; step += RING) {
         do_step(step, std::integral_constant<int, 0>{});
         if (step + 1 < n_steps) do_step(step + 1, std::integral_constant<int, 1>{});
         if (step + 2 < n_steps) do_step(step + 2, std::integral_constant<int, 2>{});
-        if constexpr (RING > 3) {
-            if (step + 3 < n_steps) do_step(step + 3, std::integral_constant<int, 3 % RING>{});
-            if (step + 4 < n_steps) do_step(step + 4, std::integral_constant<int, 4 % RING>{});
-            if (step + 5 < n_steps) do_step(step + 5, std::integral_constant<int, 5 % RING>{});
+        if (step + 3 < n_steps) do_step(step + 3, std::integral_constant<int, 3>{});
+        if constexpr (RING > 4) {
+            if (step + 4 < n_steps) do_step(step + 4, std::integral_constant<int, 4>{});
+            if (step + 5 < n_steps) do_step(step + 5, std::integral_constant<int, 5>{});
+        }
+        if constexpr (RING > 6) {
+            if (step + 6 < n_steps) do_step(step + 6, std::integral_constant<int, 6>{});
+            if (step + 7 < n_steps) do_step(step + 7, std::integral_constant<int, 7>{});
+        }
+        if constexpr (RING > 8) {
+            if (step + 8 < n_steps) do_step(step + 8, std::integral_constant<int, 8>{});
+            if (step + 9 < n_steps) do_step(step + 9, std::integral_constant<int, 9>{});
         }
     }
     // lane = key, registers = d (runs of 4): 8-byte stores into the k and v column blocks of dqkv
