@@ -152,9 +152,21 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(seed: int) -> dict:
-    """CPU oracle (pure torch, fp32) timed on this host: config P of BASELINE.json (B=2, S=512, V=133 258, full 16-layer
-    1B model), one optimizer step = forward + backward + AdamW.  Bounded sample: 1 step (1024 tokens)."""
+def cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(seed: int, warmup: int = 1, steps: int = 3) -> dict:
+    """CPU oracle (pure torch, fp32) timed on this host, as BASELINE.md §4 plans it: config P of BASELINE.json (B=2, S=512,
+    V=133 258, full 16-layer 1B model), optimizer step = forward + backward + AdamW, `warmup` untimed + `steps` timed steps on
+    different batches, mean reported.  Bounded sample: (warmup + steps) x 1024 tokens, about a minute on 16 cores."""
     from oracle import step_oracle
     from oracle.llama_oracle import OracleCEWithChunkedOutputLoss, OracleLlama
     from ssi.data import synthetic_batch
@@ -180,18 +192,43 @@ def cpu_baseline(seed: int) -> dict:
     model.set_num_output_chunks(8)
     loss_fn = OracleCEWithChunkedOutputLoss()
     opt = torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
-    batch = synthetic_batch(2, 512, 5000, seed=seed)
     t_build = time.perf_counter() - t0
-    print(f"[cpu_baseline] built in {t_build:.1f} s; timing one optimizer step (B=2, S=512) ...", file=sys.stderr, flush=True)
-    t1 = time.perf_counter()
-    lb, n = step_oracle.train_step(model, loss_fn, batch)
-    print(f"[cpu_baseline] forward+backward {time.perf_counter() - t1:.1f} s", file=sys.stderr, flush=True)
-    step_oracle.optimizer_step(model, opt, n)
-    dt = time.perf_counter() - t1
-    tokens = batch["tokens"].numel()
-    return {"value": tokens / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"1 optimizer step (fwd+bwd+AdamW) of config P: B=2 x S=512 = {tokens} tokens, fp32, V=133258, 16 layers; "
-                      f"{dt:.1f} s step, {t_build:.1f} s model build (cold, no warm-up)", "loss": lb / max(n, 1)}
+    print(f"[cpu_baseline] built in {t_build:.1f} s; {warmup} warm-up + {steps} timed optimizer steps (B=2, S=512) ...", file=sys.stderr, flush=True)
+    times, tokens, loss = [], 0, float("nan")
+    for i in range(warmup + steps):
+        batch = synthetic_batch(2, 512, 5000, seed=seed, index=i)
+        t1 = time.perf_counter()
+        lb, n = step_oracle.train_step(model, loss_fn, batch)
+        step_oracle.optimizer_step(model, opt, n)
+        dt = time.perf_counter() - t1
+        print(f"[cpu_baseline] step {i} ({'warm-up' if i < warmup else 'timed'}): {dt:.1f} s", file=sys.stderr, flush=True)
+        if i >= warmup:
+            times.append(dt)
+            tokens = batch["tokens"].numel()
+            loss = lb / max(n, 1)
+    mean = sum(times) / len(times)
+    return {"value": tokens / mean, "unit": "tokens/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
+            "sample": f"{warmup} warm-up + {steps} timed optimizer steps (fwd+bwd+AdamW) of config P: B=2 x S=512 = {tokens} tokens each, fp32, "
+                      f"V=133258, 16 layers; mean {mean:.1f} s/step (min {min(times):.1f}, max {max(times):.1f}), {t_build:.1f} s model build; "
+                      f"{cores} threads on {cpu_model_name()}", "loss": loss}
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without torchrun: start N fresh rank processes (one per GPU) through torch.distributed.run and
+    relay rank 0's JSON line and the children's exit code.  Runs before this process has made any HIP call (a process that has
+    touched the GPU must never exec or fork GPU work on this pool)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
 
 
 def main() -> int:
@@ -215,10 +252,11 @@ def main() -> int:
     args = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)  # nothing has touched the GPU yet
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
-            return 2
+        print(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        return 2
     local = int(os.environ.get("SSI_LOCAL_DEVICE", local))  # rehearsal hook: several ranks on one GPU (with SSI_DIST_BACKEND=gloo)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
@@ -297,6 +335,8 @@ def main() -> int:
         loss, _ = one_step(i)
     barrier()
     timer.enabled = True
+    if sync is not None:
+        sync.timing, sync.bytes_reduced = True, 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss, _ = one_step(args.warmup + i)
@@ -351,6 +391,10 @@ def main() -> int:
                 "other_gemm_kernels": {sym.get(k, str(k)): {"launches": v[0], "avg_ms": v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
                                        for k, v in per.items() if k != dom},
             }
+        if sync is not None:  # what crossed xGMI and how much of it the step had to wait for (rank 0's view)
+            out["comm"] = {"backend": dist.get_backend(), "library": "RCCL" if dist.get_backend() == "nccl" else dist.get_backend(),
+                           "ranks": dist.get_world_size(), "allreduce_bytes_per_step": sync.bytes_reduced / args.steps,
+                           "buckets": len(sync.buckets), "exposed_ms_per_step": sync.exposed_ms() / args.steps}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(42_831)

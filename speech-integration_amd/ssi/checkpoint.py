@@ -5,7 +5,8 @@ reference's class of the same name does (``/root/reference/ssi/checkpoint.py:209
 validation, HF<->torchtune key map with the q/k row permutation, ``step_N/`` output directories, schema-v1
 ``training_state.pt`` (``constants.py:78-89``).  ``TuneCheckpointer`` is the single-file variant used when ``checkpoint_dir`` is
 not an HF model directory: ONE safetensors file whose keys are the torchtune names the model exposes; with no weights on disk
-the model is random-initialised (seeded) — there are no Llama weights on the build/GPU image and no network.  Both expose
+it raises unless ``allow_random_init`` was set (then the model is random-initialised, seeded — there are no Llama weights on the
+build/GPU image and no network).  Both expose
 ``load_checkpoint() -> {"model": state_dict | None, ...training-state keys}``, ``save_model_checkpoint(state_dict, step)``,
 ``save_training_state(...)``, ``training_state_checkpoint``; ``make_checkpointer`` picks one."""
 
@@ -33,18 +34,33 @@ def resolve_checkpointer_output_dir(cfg, wandb_logger) -> str:
 
 
 def save_rng_states() -> dict[str, Any]:
-    state = {"python": random.getstate(), "numpy": np.random.get_state(), "torch_cpu": torch.get_rng_state()}
+    """Python / NumPy / torch generator states under the reference's keys (``/root/reference/ssi/checkpoint.py:188-197``).  The NumPy
+    Mersenne-Twister key array is stored as a tensor so that ``training_state.pt`` holds nothing but tensors and plain containers
+    and loads with ``torch.load(weights_only=True)`` (the reference's ``safe_torch_load``)."""
+    kind, keys, pos, has_gauss, cached = np.random.get_state()
+    state = {"python": random.getstate(),
+             "numpy_global": (str(kind), torch.from_numpy(np.asarray(keys, dtype=np.int64)), int(pos), int(has_gauss), float(cached)),
+             "torch_cpu": torch.get_rng_state()}
     if torch.cuda.is_available():
         state["torch_cuda"] = torch.cuda.get_rng_state_all()
     return state
 
 
 def restore_rng_states(state: dict[str, Any]) -> None:
-    random.setstate(state["python"])
-    np.random.set_state(state["numpy"])
+    py = state["python"]
+    random.setstate((py[0], tuple(py[1]), py[2]))  # lists -> tuples if a loader relaxed them
+    kind, keys, pos, has_gauss, cached = state["numpy_global"] if "numpy_global" in state else state["numpy"]
+    keys = keys.numpy() if isinstance(keys, torch.Tensor) else np.asarray(keys)
+    np.random.set_state((str(kind), keys.astype(np.uint32), int(pos), int(has_gauss), float(cached)))
     torch.set_rng_state(state["torch_cpu"])
     if "torch_cuda" in state and torch.cuda.is_available():
         torch.cuda.set_rng_state_all(state["torch_cuda"])
+
+
+def load_training_state(path: str) -> dict[str, Any]:
+    """``training_state.pt`` through the restricted unpickler only (tensors, numbers, strings, lists/tuples/dicts): nothing in the
+    file is executed (reference: ``safe_torch_load``, ``ssi/checkpoint.py:334``)."""
+    return torch.load(path, map_location="cpu", weights_only=True)
 
 
 @torch.no_grad()
@@ -65,10 +81,13 @@ def random_init_(model, seed: int, std: float = 0.02) -> None:
 class TuneCheckpointer:
     def __init__(self, checkpoint_dir: str | None = None, checkpoint_files: Any = None, config_json: Any = None,
                  output_dir: str | None = None, training_state_checkpoint: str | None = None, safe_serialization: bool = True,
-                 model_expectations: Any = None, **_: Any) -> None:
+                 model_expectations: Any = None, allow_random_init: bool = False, **_: Any) -> None:
         self.checkpoint_dir, self.output_dir = checkpoint_dir, output_dir
         self.training_state_checkpoint = training_state_checkpoint
         self.model_expectations = model_expectations
+        self.allow_random_init = bool(allow_random_init)
+        if self.training_state_checkpoint is not None and not os.path.isfile(str(self.training_state_checkpoint)):
+            raise FileNotFoundError(f"Recipe checkpoint file {self.training_state_checkpoint} not found.")
 
     def load_checkpoint(self) -> dict[str, Any]:
         out: dict[str, Any] = {MODEL_KEY: None}
@@ -77,11 +96,15 @@ class TuneCheckpointer:
             from safetensors.torch import load_file
             out[MODEL_KEY] = load_file(path)
             LOGGER.info(f"Loaded {len(out[MODEL_KEY])} tensors from {path}")
-        else:
-            LOGGER.warning(f"No {MODEL_FILENAME} under {self.checkpoint_dir!r}: the model will be random-initialised (seeded).")
+        elif self.allow_random_init:
+            LOGGER.warning(f"No {MODEL_FILENAME} under {self.checkpoint_dir!r}: checkpointer.allow_random_init is set, the model "
+                           "will be random-initialised (seeded).")
+        else:  # a mistyped or unmounted checkpoint_dir must not silently train from noise (reference: ssi/checkpoint.py:263-264)
+            raise FileNotFoundError(f"No {MODEL_FILENAME} (and no HF config.json) under checkpoint_dir={self.checkpoint_dir!r}. Point "
+                                    "checkpointer.checkpoint_dir at a model directory, or set checkpointer.allow_random_init=true to "
+                                    "train from seeded random weights.")
         if self.training_state_checkpoint is not None:
-            state = torch.load(self.training_state_checkpoint, map_location="cpu", weights_only=False)  # own file, own writer
-            out.update(state)
+            out.update(load_training_state(self.training_state_checkpoint))
         return out
 
     def save_model_checkpoint(self, state_dict: dict[str, torch.Tensor], global_step: int) -> str:
@@ -244,8 +267,6 @@ class FullModelHFCheckpointer(TuneCheckpointer):
         self._ckpt_dir, self._out_dir = Path(checkpoint_dir), Path(output_dir)
         if self._out_dir.resolve() == self._ckpt_dir.resolve() or self._ckpt_dir.resolve() in self._out_dir.resolve().parents:
             raise ValueError(f"output_dir {self._out_dir} must not lie inside checkpoint_dir {self._ckpt_dir}")
-        if self.training_state_checkpoint is not None and not Path(self.training_state_checkpoint).is_file():
-            raise FileNotFoundError(f"Recipe checkpoint file {self.training_state_checkpoint} not found.")
         self._out_dir.mkdir(parents=True, exist_ok=True)
         config_json = Path(config_json) if config_json is not None else self._ckpt_dir / LLAMA_3_2_CONFIG_RELPATH
         if not config_json.exists():
@@ -283,7 +304,7 @@ class FullModelHFCheckpointer(TuneCheckpointer):
             gc.collect()
         out: dict[str, Any] = {MODEL_KEY: hf_to_tune(merged, **self._conv_kwargs(), tie_word_embeddings=self._config.get("tie_word_embeddings", True))}
         if self.training_state_checkpoint is not None:
-            out.update(torch.load(self.training_state_checkpoint, map_location="cpu", weights_only=False))  # own file, own writer
+            out.update(load_training_state(self.training_state_checkpoint))
         return out
 
     def save_full_model(self, state_dict: dict[str, Any], output_dir: Path) -> None:
@@ -318,9 +339,12 @@ class FullModelHFCheckpointer(TuneCheckpointer):
 
 
 def make_checkpointer(**kwargs: Any):
-    """HF-format checkpointer when ``checkpoint_dir`` is an HF model directory (has config.json), else the single-file
-    torchtune-key checkpointer (random init when no weights exist on disk — the build and GPU images have none)."""
+    """HF-format checkpointer when ``checkpoint_dir`` is an HF model directory (has config.json); the single-file torchtune-key
+    checkpointer when it holds a ``model.safetensors`` this trainer wrote, or when ``allow_random_init`` is set explicitly (seeded
+    random weights: the build and GPU images hold no Llama weights).  Anything else is an error at load time, as in the reference
+    (``/root/reference/ssi/checkpoint.py:263-264``) — a wrong path never silently trains from noise."""
     d = kwargs.get("checkpoint_dir")
     if d and (Path(str(d)) / LLAMA_3_2_CONFIG_RELPATH).exists():
+        kwargs.pop("allow_random_init", None)
         return FullModelHFCheckpointer(**kwargs)
     return TuneCheckpointer(**kwargs)

@@ -58,6 +58,8 @@ class GradSync:
         self._last_range = (0, 0)
         self._comm_stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         self.bytes_reduced = 0
+        self.timing = False            # bench: time how long the compute stream sits waiting for reductions (exposed communication)
+        self._wait_events: list = []
         # token counts and the running loss travel on a communicator of their own: on the gradients' one they would queue behind
         # every bucket already issued (a communicator runs its collectives in issue order), the deferred embedding bucket included
         self.scalar_group = dist.new_group() if self.enabled else None
@@ -100,10 +102,12 @@ class GradSync:
                 self.bucket_ready(name, lo, hi)
             if defer_last and len(self._pending) > 1:
                 self._deferred = (self._pending.pop(), self._last_range)
+            mark = self._mark()
             for work in self._pending:
                 work.wait()
-            if self._comm_stream is not None:
+            if self._comm_stream is not None and self._deferred is None:
                 torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._comm_stream)
+            self._mark(mark)
         self._pending.clear()
         self._done.clear()
 
@@ -113,8 +117,29 @@ class GradSync:
 
     def finish_deferred(self) -> None:
         if self._deferred is not None:
+            mark = self._mark()
             self._deferred[0].wait()
+            if self._comm_stream is not None:
+                torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._comm_stream)
+            self._mark(mark)
             self._deferred = None
+
+    def _mark(self, start=None):
+        """Timing events on the compute stream around a wait (only when ``timing``): the gap between them is the time the stream
+        had nothing to run but the reductions."""
+        if not (self.timing and self._comm_stream is not None):
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.flat_grad.device))
+        if start is not None:
+            self._wait_events.append((start, ev))
+        return ev
+
+    def exposed_ms(self) -> float:
+        """Sum of the timed waits since the last call (synchronise the device first)."""
+        total = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        self._wait_events.clear()
+        return float(total)
 
     @classmethod
     def for_module(cls, module: torch.nn.Module, group=None) -> "ModuleGradSync":

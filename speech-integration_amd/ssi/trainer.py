@@ -45,7 +45,7 @@ from .optimizer import clip_grad_norm_, scale_grads, setup_optimizer
 from .train_utils import (count_token_types, count_token_types_async, get_token_type_ranges, resume_training_state,
                           validate_resume_hparams, validate_train_cfg)
 
-__all__ = ["Trainer", "TrainingGeometry"]
+__all__ = ["Trainer", "TrainingGeometry", "resume_position"]
 
 LOGGER = logging.getLogger(__name__)
 
@@ -104,6 +104,14 @@ class TrainingGeometry:
                    gradient_accumulation_steps=ga, world_size=world_size)
 
 
+def resume_position(global_step: int, steps_per_epoch: int, gradient_accumulation_steps: int) -> tuple[int, int]:
+    """Where a run that has completed ``global_step`` optimizer steps re-enters the data: ``(epochs already run, micro-batches of
+    the current epoch to skip)`` — the arithmetic the reference does inline in ``train()`` (``trainer.py:330-336``) and pins in
+    ``tests/test_checkpoint.py:203-240``."""
+    epochs_run, steps_into_epoch = divmod(int(global_step), int(steps_per_epoch))
+    return epochs_run, steps_into_epoch * int(gradient_accumulation_steps)
+
+
 class Trainer:
     """Usage (as the reference): ``t = Trainer(cfg); t.setup(); t.train(); t.cleanup()``."""
 
@@ -142,6 +150,7 @@ class Trainer:
         self.t_step_start: float = 0.0
         self._grad_norm: float | None = None
         self._loss_log: list[float] | None = None
+        self._type_counts_window: defaultdict[str, int] = defaultdict(int)  # this rank's counts since the last optimizer step
         # data parallel
         self.grad_sync: GradSync | None = None
         self._resume_state: dict[str, Any] | None = None
@@ -278,8 +287,7 @@ class Trainer:
         self.t_train_start = time.perf_counter()
         self.t_step_start = time.perf_counter()
         self._reset_step_accumulators()
-        epochs_run = self.global_step // self.geometry.steps_per_epoch
-        batches_to_skip = (self.global_step % self.geometry.steps_per_epoch) * self.cfg.gradient_accumulation_steps
+        epochs_run, batches_to_skip = resume_position(self.global_step, self.geometry.steps_per_epoch, self.cfg.gradient_accumulation_steps)
         if self._resume_rng_state is not None:
             from .checkpoint import restore_rng_states
             restore_rng_states(self._resume_rng_state)
@@ -338,22 +346,29 @@ class Trainer:
         if on_gpu:
             host = torch.cat((counts_dev.to(torch.float64), loss_batch.detach().to(torch.float64).reshape(1))).tolist()
             names = list(self.token_type_ranges) + ["total"]
-            for tt, c in zip(names, host):
-                self.token_type_counts_total[tt] += int(c)
+            counts_host = {tt: int(c) for tt, c in zip(names, host)}
             num_tokens_iter, loss_value = int(host[len(names)]), float(host[-1])
         else:
-            for tt, c in counts_host.items():
-                self.token_type_counts_total[tt] += c
             num_tokens_iter, loss_value = int(n_valid.item()), float(loss_batch.item())
+        for tt, c in counts_host.items():
+            self.token_type_counts_total[tt] += c
+            self._type_counts_window[tt] += c
         self.num_tokens_step += num_tokens_iter
         self.loss_running += loss_value
 
     def _optimizer_step(self, epoch: int, iter_idx: int) -> None:
         """Accumulation boundary (``trainer.py:397-424``): [all-reduce] -> scale -> clip -> AdamW -> LR -> counters."""
         if self.grad_sync is not None:
-            self.num_tokens_step, self.loss_running = (lambda v: (int(round(v[0])), float(v[1])))(
-                all_reduce_scalars([self.num_tokens_step, self.loss_running], self.device, group=self.grad_sync.scalar_group))
+            # one small collective: token count, running loss and the window's token-type counts (tokens_total is global, so the
+            # per-type totals must be too: every rank adds what the OTHER ranks saw in this window)
+            kinds = sorted(self._type_counts_window)
+            summed = all_reduce_scalars([self.num_tokens_step, self.loss_running, *(self._type_counts_window[k] for k in kinds)],
+                                        self.device, group=self.grad_sync.scalar_group)
+            self.num_tokens_step, self.loss_running = int(round(summed[0])), float(summed[1])
+            for k, v in zip(kinds, summed[2:]):
+                self.token_type_counts_total[k] += int(round(v)) - self._type_counts_window[k]
             self.grad_sync.finish(defer_last=self.cfg.clip_grad_norm is None)  # the embedding bucket lands under the AdamW of the rest
+        self._type_counts_window.clear()
         if self.num_tokens_step == 0:
             LOGGER.warning("No non-ignored tokens in accumulation window; skipping optimizer step.")
             self.optimizer.zero_grad(set_to_none=True)

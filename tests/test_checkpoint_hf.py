@@ -108,3 +108,42 @@ def test_hf_checkpointer_validation_errors(tmp_path):
         FullModelHFCheckpointer(src, ["model-00001-of-00001.safetensors"], output_dir=tmp_path / "o2").save_full_model({MODEL_KEY: {}}, tmp_path / "o2" / "x")
     # a directory without config.json is not an HF model directory: the single-file torchtune-key checkpointer is used
     assert type(make_checkpointer(checkpoint_dir=str(tmp_path / "o"), output_dir=str(tmp_path / "o4"))) is TuneCheckpointer
+
+
+def test_missing_weights_raise_unless_random_init_is_asked_for(tmp_path):
+    """A checkpoint_dir with neither config.json nor model.safetensors is an error (reference: ssi/checkpoint.py:263-264), not a
+    silent random initialisation; ``allow_random_init`` is the explicit opt-in."""
+    ck = make_checkpointer(checkpoint_dir=str(tmp_path / "typo"), output_dir=str(tmp_path / "o"))
+    with pytest.raises(FileNotFoundError, match="allow_random_init"):
+        ck.load_checkpoint()
+    ck = make_checkpointer(checkpoint_dir=str(tmp_path / "typo"), output_dir=str(tmp_path / "o"), allow_random_init=True)
+    assert ck.load_checkpoint()[MODEL_KEY] is None
+    with pytest.raises(FileNotFoundError, match="Recipe checkpoint"):
+        make_checkpointer(checkpoint_dir=str(tmp_path / "typo"), output_dir=str(tmp_path / "o"), allow_random_init=True,
+                          training_state_checkpoint=str(tmp_path / "nope.pt"))
+
+
+def test_training_state_round_trips_through_the_restricted_loader(tmp_path):
+    """training_state.pt holds tensors and plain containers only: it loads with weights_only=True, carries the reference's RNG keys
+    (python, numpy_global, torch_cpu) and restores the three generators exactly."""
+    import random
+
+    import numpy as np
+    from ssi.checkpoint import TuneCheckpointer, restore_rng_states
+    random.seed(5), np.random.seed(6), torch.manual_seed(7)
+    np.random.standard_normal(3)  # leaves a cached gaussian in the legacy generator
+    ck = TuneCheckpointer(checkpoint_dir=None, output_dir=str(tmp_path), allow_random_init=True)
+    opt = torch.optim.AdamW([torch.nn.Parameter(torch.ones(3))], lr=1e-3)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda n: 1.0)
+    path = ck.save_training_state(optimizer_state_dict=opt.state_dict(), lr_scheduler_state_dict=sched.state_dict(), global_step=4, seed=1,
+                                  training_hparams={"batch_size": 2}, consumed_samples=8,
+                                  cumulative_metrics={"tokens_train_total": 10, "token_type_counts": {"text": 3}, "wall_clock_seconds": 1.5})
+    want = (random.random(), np.random.standard_normal(2).tolist(), np.random.randint(0, 100), torch.rand(2))
+    state = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(state["rng_state"]) >= {"python", "numpy_global", "torch_cpu"} and state["global_step"] == 4
+    random.seed(0), np.random.seed(0), torch.manual_seed(0)
+    restore_rng_states(state["rng_state"])
+    got = (random.random(), np.random.standard_normal(2).tolist(), np.random.randint(0, 100), torch.rand(2))
+    assert got[:3] == want[:3] and torch.equal(got[3], want[3])
+    resumed = TuneCheckpointer(checkpoint_dir=None, output_dir=str(tmp_path), allow_random_init=True, training_state_checkpoint=path).load_checkpoint()
+    assert resumed["consumed_samples"] == 8 and resumed["cumulative_metrics"]["token_type_counts"] == {"text": 3}

@@ -1,0 +1,36 @@
+"""GPU, >= 2 devices: the data-parallel step over RCCL (torch.distributed backend "nccl") — per-bucket all-reduce on a side stream
+during backward, scalar communicator, deferred embedding bucket, dynamic GEMM tile order — equals the single-process step over the
+union of the micro-batches.  Skipped on a one-GPU box (the driver's test box has one GPU); the same worker is rehearsed there by hand
+with two ranks sharing the GPU over gloo (see tests/workers/dp_step_worker.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_rank_rccl_step_equals_single_process_step(tmp_path):
+    if torch.cuda.device_count() < 2:   # device_count() does not initialise the GPU
+        pytest.skip("needs >= 2 GPUs")
+    if torch.cuda.is_initialized():
+        pytest.skip("this process already holds the GPU: ranks must be started from a process that has not touched it")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "dp.json"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SSI_DIST_BACKEND", None)
+    env.pop("SSI_LOCAL_DEVICE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "workers", "dp_step_worker.py"), "--out", str(out)]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-4000:] + proc.stderr[-4000:]
+    verdict = json.loads(out.read_text())
+    assert verdict["backend"] == "nccl" and verdict["world"] == 2 and verdict["ok_all_ranks"], verdict

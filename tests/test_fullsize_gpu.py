@@ -1,0 +1,254 @@
+"""GPU parity at the sizes the headline number is measured at (BASELINE.json configs A, A', C, E, P), for the kernels bench.py times:
+
+* the whole 1B model (16 layers, D = 2048, V = 133 258) against the CPU oracle on config P's batch (B = 2, S = 512): fp32 (generic
+  kernels) and bf16 (MFMA GEMMs, split-K weight gradients, MFMA attention, fused LM head + cross-entropy) from the SAME weights;
+* the persistent MFMA GEMM on the step's own shapes (LM head NT / NN / TN at N = 133 376 and 136 704, the split-K weight gradients
+  of the square projections, the K = 16 384 weight gradients) — exact on small-integer operands;
+* MFMA attention forward / backward at S = 4096 and S = 8192 with 32 query / 8 kv heads, plain causal and packed with 440-1100-token
+  documents (the `block_to_work` map at 32 and 64 key groups), against torch SDPA in fp32 on the CPU.
+
+Tolerances are written at each assert (north star: loss / logits within 1e-3 relative in fp32)."""
+import copy
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 1. Whole model, config P dimensions
+# ---------------------------------------------------------------------------------------------------------------------
+def _full_config(n_dsus=5000):
+    from ssi.llama_configs import configllama3_2_1b
+    cfg = copy.deepcopy(configllama3_2_1b)
+    cfg.n_dsus, cfg.modality_tokens = n_dsus, True
+    return cfg
+
+
+def _seeded_full_state_dict(params, seed):
+    """N(0, 0.02^2) weights, norm scales 1 + 0.1 N(0,1), every value rounded to bf16 so that the fp32 oracle, the fp32 HIP model and
+    the bf16 HIP model hold bit-identical weights (what differs is then only the arithmetic under test)."""
+    from oracle.llama_oracle import OracleLlama
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in OracleLlama(**params, rope_cache_len=8).state_dict().items()}
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in shapes.items():
+        t = torch.randn(shape, generator=g)
+        t = (1.0 + 0.1 * t) if name.endswith("scale") else 0.02 * t
+        sd[name] = t.bfloat16().float()
+    return sd
+
+
+@pytest.fixture(scope="module")
+def full_size_reference():
+    """Oracle forward + backward of the full model on config P's batch (about 15 s on the GPU box's 16 host cores)."""
+    from oracle.llama_oracle import OracleCEWithChunkedOutputLoss, OracleLlama
+    from oracle.llama_oracle import compute_loss as oracle_loss
+    from ssi.data import synthetic_batch
+    cfg = _full_config()
+    params = cfg.parameters
+    sd = _seeded_full_state_dict(params, 2024)
+    batch = synthetic_batch(2, 512, 5000, seed=42_831)
+    with torch.device("meta"):
+        ref = OracleLlama(**params, rope_cache_len=512)
+    rope = ref.rope.clone()
+    ref = ref.to_empty(device="cpu")
+    ref.rope = rope
+    ref.load_state_dict(sd)
+    ref.set_num_output_chunks(8)
+    loss = oracle_loss(batch, ref, OracleCEWithChunkedOutputLoss())
+    loss.backward()
+    rows = [(0, 0), (0, 17), (0, 255), (0, 511), (1, 1), (1, 300), (1, 448), (1, 510)]
+    with torch.no_grad():
+        hn = ref.forward_hidden(batch["tokens"])
+        logit_rows = torch.stack([F.linear(hn[b, s], ref.tok_embeddings.weight) for b, s in rows])
+    grads = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    n_shifted = int((torch.hstack((batch["labels"][..., 1:], torch.full_like(batch["labels"][..., -1:], -100))) != -100).sum())
+    out = dict(cfg=cfg, params=params, sd=sd, batch=batch, loss=float(loss), rows=rows, logit_rows=logit_rows, grads=grads, n_shifted=n_shifted)
+    del ref
+    return out
+
+
+@pytest.mark.parametrize("dtype_name", ["fp32", "bf16"])
+def test_full_size_model_matches_the_cpu_oracle(full_size_reference, dtype_name):
+    from ssi.loss import CEWithChunkedOutputLoss, compute_loss
+    from ssi.model import HipLlamaDecoder
+    R = full_size_reference
+    dtype = torch.float32 if dtype_name == "fp32" else torch.bfloat16
+    model = HipLlamaDecoder(**R["params"], dtype=dtype, device=DEV, rope_cache_len=512)
+    model.load_state_dict(R["sd"])
+    held = model.state_dict()
+    for k in ("tok_embeddings.weight", "layers.7.attn.k_proj.weight", "layers.15.mlp.w3.weight", "norm.scale"):
+        assert torch.equal(held[k].float().cpu(), R["sd"][k]), k   # bf16-representable weights: both dtypes hold them exactly
+    model.set_num_output_chunks(8)
+    assert model._mfma_shapes() == (dtype == torch.bfloat16)
+    batch = {k: v.to(DEV) for k, v in R["batch"].items()}
+    model.train()
+    loss = compute_loss(batch, model, CEWithChunkedOutputLoss())
+    loss.backward()
+    rel = abs(loss.item() - R["loss"]) / abs(R["loss"])
+    tol_loss, tol_logit, tol_grad = (1e-4, 1e-3, 2e-3) if dtype_name == "fp32" else (1e-2, 3e-2, 6e-2)
+    print(f"[full-size {dtype_name}] loss {loss.item():.6f} vs oracle {R['loss']:.6f}: rel {rel:.2e} (tolerance {tol_loss})")
+    assert rel <= tol_loss
+    worst, worst_key = 0.0, None
+    for k, p in model.named_parameters():
+        g, g_ref = p.grad.float().cpu(), R["grads"][k]
+        err = float((g - g_ref).norm() / g_ref.norm())
+        if err > worst:
+            worst, worst_key = err, k
+        assert err <= tol_grad, f"{k}: relative gradient error {err}"
+        nrm = float(g.norm()) / float(g_ref.norm())
+        assert abs(nrm - 1.0) <= tol_grad, f"{k}: gradient norm ratio {nrm}"
+    print(f"[full-size {dtype_name}] worst relative gradient error {worst:.2e} ({worst_key})")
+    # logits through the public forward (8 chunks), at sampled positions
+    model.eval()
+    with torch.no_grad():
+        logits = torch.cat(model(tokens=batch["tokens"]), dim=1)
+    got = torch.stack([logits[b, s].float().cpu() for b, s in R["rows"]])
+    err = float((got - R["logit_rows"]).abs().max())
+    scale = float(R["logit_rows"].abs().max())
+    print(f"[full-size {dtype_name}] logits max-abs error {err:.3e} vs max |logit| {scale:.3f} (tolerance {tol_logit} x)")
+    assert err <= tol_logit * scale
+    assert int(torch.argmax(got, -1).eq(torch.argmax(R["logit_rows"], -1)).sum()) >= (8 if dtype_name == "fp32" else 6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 2. The step's own GEMM shapes, exact on small integers
+# ---------------------------------------------------------------------------------------------------------------------
+def _sparse_ints(shape, p_nonzero, seed):
+    """Entries in {-1, 0, 1}, nonzero with probability p: products and partial sums are exact in fp32, and with K p^2 small enough
+    nearly every result is an integer of magnitude <= 256, which bf16 holds exactly."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    sign = torch.randint(0, 2, shape, generator=g, device=DEV, dtype=torch.int8) * 2 - 1
+    keep = torch.rand(shape, generator=g, device=DEV) < p_nonzero
+    return (sign * keep).to(torch.bfloat16)
+
+
+STEP_SHAPES = [
+    # (what, layout, M, N, K, splits)                                                  NT=0: A[M,K] B[N,K];  NN=1: B[K,N];  TN=2: A[K,M] B[K,N]
+    ("LM head forward, V=133258", 0, 16384, 133_376, 2048, 1),
+    ("LM head forward, V=136450 (config A')", 0, 16384, 136_704, 2048, 1),
+    ("LM head data gradient", 1, 16384, 2048, 133_376, 1),
+    ("LM head weight gradient", 2, 133_376, 2048, 16384, 1),
+    ("LM head weight gradient, V=130306 (config E)", 2, 130_560, 2048, 16384, 1),
+    ("dW_qkv (split-K)", 2, 3072, 2048, 16384, 0),
+    ("dW_o (split-K)", 2, 2048, 2048, 16384, 0),
+    ("dW13", 2, 16384, 2048, 16384, 1),
+    ("dW2", 2, 2048, 8192, 16384, 1),
+    ("W2 forward", 0, 16384, 2048, 8192, 1),
+    ("gate-up data gradient", 1, 16384, 2048, 16384, 1),
+]
+
+
+@pytest.mark.parametrize("what,layout,M,N,K,splits", STEP_SHAPES, ids=[s[0] for s in STEP_SHAPES])
+def test_gemm_at_the_training_step_shapes_is_exact_on_integers(what, layout, M, N, K, splits):
+    from ssi import _lib, ops
+    p = min(0.5, math.sqrt(4096.0 / K))          # K p^2 = 4096 -> sums ~ N(0, 64^2): |sum| <= 256 for all but ~1e-4 of the entries
+    a = _sparse_ints((M, K) if layout in (0, 1) else (K, M), p, 101)
+    b = _sparse_ints((N, K) if layout == 0 else (K, N), p, 102)
+    ref = (a.float() @ b.float().t()) if layout == 0 else ((a.float() @ b.float()) if layout == 1 else (a.float().t() @ b.float()))
+    exact = ref.abs() <= 256
+    assert float(exact.float().mean()) > 0.99
+    prev = ops.set_impl(_lib.IMPL_MFMA)   # the MFMA path or an error: no silent fallback to the generic kernel
+    try:
+        c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        if splits == 0:
+            splits = ops.splitk_choice(M, N, K)
+            assert splits > 1, "the model splits this weight gradient over K"
+            ws = torch.empty(splits * M * N, dtype=torch.float32, device=DEV)
+            ops.gemm_splitk(layout, a, b, c, splits, ws)
+        else:
+            ops.gemm(layout, a, b, c)
+        assert torch.equal(c.float()[exact], ref[exact]), f"{what}: not exact"
+        assert torch.isfinite(c.float()).all()
+        # accumulate + device-side alpha, as the backward pass calls it (dW += alpha * dY^T X)
+        c0 = torch.randint(-2, 3, (M, N), device=DEV, generator=torch.Generator(device=DEV).manual_seed(103)).to(torch.bfloat16)
+        c1 = c0.clone()
+        alpha = torch.tensor([0.5], dtype=torch.float32, device=DEV)
+        if splits > 1:
+            ops.gemm_splitk(layout, a, b, c1, splits, ws, alpha_dev=alpha, accumulate=True)
+        else:
+            ops.gemm(layout, a, b, c1, alpha_dev=alpha, accumulate=True)
+        want = (0.5 * ref).bfloat16().float() + c0.float()      # the product is rounded to bf16, then added (two roundings, as F.linear then +)
+        ok = exact & ((0.5 * ref) == (0.5 * ref).bfloat16().float()) & (want == want.bfloat16().float())  # exact under either rounding order
+        assert float(ok.float().mean()) > 0.5
+        assert torch.equal(c1.float()[ok], want[ok]), f"{what}: accumulate form not exact"
+    finally:
+        ops.set_impl(prev)
+        del a, b, ref, exact, c
+        torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 3. Attention at S = 4096 / 8192 with the model's head counts
+# ---------------------------------------------------------------------------------------------------------------------
+def _documents(S, seed, lo=440, hi=1100):
+    g = torch.Generator().manual_seed(seed)
+    lens, left = [], S
+    while left > 0:
+        n = min(left, int(torch.randint(lo, hi + 1, (1,), generator=g)))
+        lens.append(n)
+        left -= n
+    return lens
+
+
+@pytest.mark.parametrize("S", [4096, 8192])
+@pytest.mark.parametrize("packed", [False, True])
+def test_attention_mfma_long_rows_32_heads(S, packed):
+    from ssi import _lib, ops
+    from test_kernels_gpu import _doc_arrays, _sdpa_block_ref, _sdpa_ref, rnd
+    B, H, KV, hd = 1, 32, 8, 64
+    qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=111)
+    qkv[S // 2 + 3, H * hd: H * hd + hd] *= 6.0
+    do = rnd(B * S, H * hd, dtype=torch.bfloat16, seed=112)
+    qr = qkv.float().clone().requires_grad_(True)
+    ds = de = None
+    if packed:
+        rows = [_documents(S, 113)]
+        assert len(rows[0]) >= S // 1100
+        ds, de = (t.to(DEV) for t in _doc_arrays(rows, S))
+        oref = _sdpa_block_ref(qr, B, S, H, KV, hd, rows)
+    else:
+        oref = _sdpa_ref(qr, B, S, H, KV, hd)
+    oref.backward(do.float())
+    prev = ops.set_impl(_lib.IMPL_MFMA)
+    try:
+        x, dout = qkv.to(DEV), do.to(DEV)
+        out = torch.full((B * S, H * hd), float("nan"), dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+        ops.attn_fwd(x, out, lse, B, S, H, KV, hd, ds, de)
+        dqkv = torch.full_like(x, float("nan"))
+        delta = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+        ops.attn_bwd(x, out, dout, lse, dqkv, delta, B, S, H, KV, hd, ds, de)
+        out2 = torch.empty_like(out)
+        ops.attn_fwd(x, out2, lse, B, S, H, KV, hd, ds, de)
+        d2 = torch.empty_like(x)
+        ops.attn_bwd(x, out2, dout, lse, d2, delta, B, S, H, KV, hd, ds, de)
+    finally:
+        ops.set_impl(prev)
+    assert torch.equal(out, out2) and torch.equal(dqkv, d2), "not bitwise reproducible"
+    out, dqkv = out.cpu().float(), dqkv.cpu().float()
+    assert torch.isfinite(out).all() and torch.isfinite(dqkv).all()
+    torch.testing.assert_close(out, oref.detach(), rtol=2e-2, atol=2e-2)
+    # the log-sum-exp the backward reads, against fp32 math on sampled heads
+    q = qr.detach()[:, : H * hd].view(S, H, hd)
+    k = qr.detach()[:, H * hd:(H + KV) * hd].view(S, KV, hd)
+    lse = lse.cpu().view(H, S)
+    for h in (0, 13, 31):
+        s = (q[:, h] @ k[:, h // (H // KV)].t()) / math.sqrt(hd)
+        mask = torch.ones(S, S, dtype=torch.bool).tril()
+        if packed:
+            dsr = ds.cpu().long()
+            mask &= torch.arange(S)[None, :] >= dsr[:, None]
+        want = torch.logsumexp(s.masked_fill(~mask, float("-inf")), dim=-1)
+        torch.testing.assert_close(lse[h], want, rtol=1e-4, atol=2e-3)
+    scale = float(qr.grad.abs().max())
+    assert float((dqkv - qr.grad).abs().max()) <= 3e-2 * scale
+    rel = float((dqkv - qr.grad).norm() / qr.grad.norm())
+    print(f"[attention S={S} packed={packed}] dqkv relative error {rel:.2e}")
+    assert rel <= 1.5e-2

@@ -263,3 +263,22 @@ def test_compute_loss_does_not_mutate_batch_and_routes_generic():
     out = compute_loss(batch, model, LossFn())
     assert float(out) == 1.5 and torch.equal(batch["labels"], labels)
     assert seen["labels"].tolist() == [2, 3, -100, -100] and seen["logits"].shape == (4, 10)
+
+
+@pytest.mark.parametrize("global_step,steps_per_epoch,ga,want", [
+    (150, 500, 4, (0, 600)),      # mid-epoch (reference tests/test_checkpoint.py:203-210)
+    (500, 500, 4, (1, 0)),        # exact epoch boundary (:213-220)
+    (0, 500, 4, (0, 0)),          # fresh start (:223-230)
+    (1249, 500, 2, (2, 498)),
+])
+def test_resume_position_arithmetic(global_step, steps_per_epoch, ga, want):
+    from ssi.trainer import resume_position
+    assert resume_position(global_step, steps_per_epoch, ga) == want
+
+
+@pytest.mark.parametrize("global_step", [0, 1, 249, 499, 500, 501, 999])
+def test_resume_position_skips_less_than_an_epoch(global_step):
+    """reference tests/test_checkpoint.py:238-243"""
+    from ssi.trainer import resume_position
+    _, skip = resume_position(global_step, 500, 4)
+    assert 0 <= skip < 500 * 4 and skip % 4 == 0

@@ -163,7 +163,7 @@ def test_trainer_three_steps_match_cpu_step_oracle(tmp_path, dtype_name, tol):
         "data=sft/mls-speechtokenizer-rvq_0", f"dtype={dtype_name}", "max_steps=3", "gradient_accumulation_steps=2",
         "tokenizer.max_seq_len=96", "data.train.dataset.n_samples=16", "data.dev.dataset.n_samples=4", "eval_steps=3", "save_steps=3",
         "lr_scheduler.num_warmup_steps=2", "optimizer.lr=1e-3", f"output_dir={tmp_path}", f"checkpointer.output_dir={tmp_path}/ckpt",
-        f"checkpointer.checkpoint_dir={tmp_path}/none", "data.train.shuffle=false",
+        f"checkpointer.checkpoint_dir={tmp_path}/none", "checkpointer.allow_random_init=true", "data.train.shuffle=false",
     ])
     cfg.model_overrides = {"num_layers": 2, "num_heads": 4, "num_kv_heads": 2, "embed_dim": 64, "intermediate_dim": 128,
                            "max_seq_len": 256, "_base_vocab_size_txt": 300, "_n_special_txt": 16}
@@ -453,7 +453,7 @@ def test_trainer_on_sft_samples_from_a_json_file_and_a_tokenizer_file(tmp_path, 
     cfg = compose(os.path.join(PKG, "conf"), "sft", [
         "data=sft/mls-speechtokenizer-rvq_0", "dtype=fp32", "max_steps=2", "gradient_accumulation_steps=1", "tokenizer.max_seq_len=128",
         "eval_steps=2", "save_steps=100", "lr_scheduler.num_warmup_steps=1", "optimizer.lr=1e-3", f"output_dir={tmp_path}",
-        f"checkpointer.output_dir={tmp_path}/ckpt", f"checkpointer.checkpoint_dir={tmp_path}/none", "data.train.shuffle=false",
+        f"checkpointer.output_dir={tmp_path}/ckpt", f"checkpointer.checkpoint_dir={tmp_path}/none", "checkpointer.allow_random_init=true", "data.train.shuffle=false",
         f"tokenizer.path={tmp_path}/tokenizer.model", "tokenizer.verbose=false",
         "data.train.dataset.source=json", "data.dev.dataset.source=json", "data.train.dataset.n_samples=null", "data.dev.dataset.n_samples=4",
         "data.dev.dataset.split=train", f"data.train.packed={'true' if packed else 'false'}", "data.train.dataloader.batch_size=2",

@@ -1,0 +1,171 @@
+"""GPU: the trainer's behavioural contracts the reference pins in its own tests, on the HIP model.
+
+* resume equivalence (reference tests/test_resume_equivalence.py:226-297): 8 steps uninterrupted == 4 steps, save, rebuild from
+  ``step_4/`` + ``training_state.pt``, 4 more — losses bit-equal, in fp32 and in bf16 (every kernel on the path is deterministic);
+* dev loss (reference ssi/eval.py:24-41): ``Trainer._evaluate()`` against the oracle's sum(loss_b * n_b) / sum(n_b) on the same batches;
+* the CPT route (``config_name=cpt``: labels = tokens, TextCompletion-shaped batches) with global-norm clipping through
+  ``Trainer.train()`` against the CPU step oracle — also the only place the clip path runs end to end on the GPU."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+SMALL = {"num_layers": 2, "num_heads": 4, "num_kv_heads": 2, "embed_dim": 64, "intermediate_dim": 128, "max_seq_len": 256,
+         "_base_vocab_size_txt": 300, "_n_special_txt": 16}
+MFMA_SMALL = {"num_layers": 2, "num_heads": 4, "num_kv_heads": 2, "embed_dim": 256, "intermediate_dim": 512, "max_seq_len": 512,
+              "_base_vocab_size_txt": 300, "_n_special_txt": 16}
+
+
+class _Remap:
+    """The synthetic generator draws ids from the production vocabulary layout; fold them into the shrunken test vocabulary."""
+
+    def __init__(self, loader, vocab):
+        self.loader, self.dataset, self.vocab = loader, loader.dataset, vocab
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for b in self.loader:
+            tok = b["tokens"] % self.vocab
+            yield {"tokens": tok, "labels": torch.where(b["labels"] == -100, b["labels"], tok)}
+
+
+def _trainer(tmp, name, config_name="sft", dtype="fp32", overrides=(), model=SMALL, seq=96):
+    from conftest import PKG
+    from ssi.config import compose
+    from ssi.train_utils import resolve_n_dsus
+    from ssi.trainer import Trainer, set_seed
+    from ssi.constants import SEED
+    out = tmp / name
+    data = "sft/mls-speechtokenizer-rvq_0" if config_name == "sft" else "cpt/mls-speechtokenizer-rvq_0"
+    cfg = compose(os.path.join(PKG, "conf"), config_name, [
+        f"data={data}", f"dtype={dtype}", f"tokenizer.max_seq_len={seq}", "data.train.dataloader.batch_size=2", "data.dev.dataloader.batch_size=2",
+        "data.train.dataset.n_samples=24", "data.dev.dataset.n_samples=6", "gradient_accumulation_steps=2", "eval_steps=1000", "save_steps=1000",
+        "lr_scheduler.num_warmup_steps=100", "optimizer.lr=2e-2", f"output_dir={out}", f"checkpointer.output_dir={out}/checkpoints",
+        f"checkpointer.checkpoint_dir={out}/none", "checkpointer.allow_random_init=true", *overrides])
+    cfg.model_overrides = dict(model)
+    cfg.speech.n_dsus = 50
+    cfg.data.n_dsus = 50
+    resolve_n_dsus(cfg)
+    set_seed(SEED)
+    t = Trainer(cfg)
+    t.setup()
+    V = t._llama_config.vocab_size
+    t.data_train, t.data_dev = _Remap(t.data_train, V), _Remap(t.data_dev, V)
+    t._loss_log = []
+    return t
+
+
+@pytest.mark.parametrize("dtype,model", [("fp32", SMALL), ("bf16", MFMA_SMALL)])
+def test_resumed_losses_match_uninterrupted(tmp_path, dtype, model):
+    total, save_at = 8, 4   # 24 samples / batch 2 / grad-accum 2 = 6 steps per epoch: the resume lands mid-epoch, the run crosses an epoch
+    seq = 96 if dtype == "fp32" else 128
+    full = _trainer(tmp_path, "full", dtype=dtype, model=model, seq=seq, overrides=[f"max_steps={total}"])
+    assert full.geometry.steps_per_epoch == 6
+    full.train()
+    losses_full = list(full._loss_log)
+    final_full = {k: v.detach().clone() for k, v in full.model.state_dict().items()}
+    full.cleanup()
+    assert len(losses_full) == total and len(set(losses_full)) == total
+    del full
+
+    b1 = _trainer(tmp_path, "b1", dtype=dtype, model=model, seq=seq, overrides=[f"max_steps={save_at}", f"save_steps={save_at}", f"eval_steps={save_at}"])
+    b1.train()
+    assert b1._loss_log == losses_full[:save_at], "pre-resume losses differ"
+    b1.cleanup()
+    ckpt = tmp_path / "b1" / "checkpoints"
+    assert (ckpt / "training_state.pt").exists() and (ckpt / f"step_{save_at}" / "model.safetensors").exists()
+    del b1
+
+    b2 = _trainer(tmp_path, "b2", dtype=dtype, model=model, seq=seq, overrides=[
+        f"max_steps={total}", f"checkpointer.checkpoint_dir={ckpt}/step_{save_at}", "checkpointer.allow_random_init=false",
+        f"checkpointer.training_state_checkpoint={ckpt}/training_state.pt"])
+    assert b2.global_step == save_at and b2.consumed_samples == save_at * 2 * 2 and b2.optimizer._step_count == save_at
+    assert b2.tokens_train_total > 0 and dict(b2.token_type_counts_total)
+    assert float(b2.optimizer._exp_avg.abs().max()) > 0   # the moments arrived in the flat buffers
+    b2.train()
+    print("full   ", losses_full, "\nresumed", b2._loss_log)
+    assert b2._loss_log == losses_full[save_at:], "losses after the resume differ from the uninterrupted run"
+    assert b2.global_step == total
+    for k, v in b2.model.state_dict().items():
+        assert torch.equal(v, final_full[k]), k       # same weights, bit for bit, after 8 steps either way
+    b2.cleanup()
+    # a changed batch size breaks the step-to-data mapping: refused unless force_resume (reference train_utils.py:110-126)
+    with pytest.raises(ValueError, match="batch_size"):
+        _trainer(tmp_path, "b3", dtype=dtype, model=model, seq=seq, overrides=[
+            f"max_steps={total}", f"checkpointer.checkpoint_dir={ckpt}/step_{save_at}", "data.train.dataloader.batch_size=3",
+            f"checkpointer.training_state_checkpoint={ckpt}/training_state.pt"])
+
+
+def test_dev_loss_matches_the_oracle(tmp_path):
+    from oracle.llama_oracle import OracleCEWithChunkedOutputLoss, OracleLlama
+    from oracle.llama_oracle import compute_loss as oracle_loss
+    t = _trainer(tmp_path, "dev", overrides=["max_steps=1", "data.dev.dataset.n_samples=7", "data.dev.dataset.fixed_len=false"])
+    dev_batches = [{k: v.clone() for k, v in b.items()} for b in t.data_dev]
+    assert len(dev_batches) == 4 and dev_batches[-1]["tokens"].shape[0] == 1        # ragged last batch (drop_last: false)
+    ref = OracleLlama(**t._llama_config.parameters, rope_cache_len=256)
+    ref.load_state_dict({k: v.detach().float().cpu() for k, v in t.model.state_dict().items()})
+    ref.set_num_output_chunks(8)
+    num, den = 0.0, 0
+    with torch.no_grad():
+        for b in dev_batches:
+            n_b = int((b["labels"] != -100).sum())                                    # UNSHIFTED count (ssi/eval.py:33-38)
+            num += float(oracle_loss(b, ref, OracleCEWithChunkedOutputLoss())) * n_b
+            den += n_b
+    got = t._evaluate()
+    print(f"dev loss {got:.7f} vs oracle {num / den:.7f}")
+    assert abs(got - num / den) <= 1e-5 * abs(num / den)
+    assert t.model.training                                                           # back in training mode afterwards
+    # the value logged by the training loop at an eval step is that same number
+    t2 = _trainer(tmp_path, "dev2", overrides=["max_steps=1", "eval_steps=1", "save_steps=1", "optimizer.lr=0.0",
+                                               "data.dev.dataset.n_samples=7", "data.dev.dataset.fixed_len=false"])
+    t2.train()
+    assert t2.wandb_logger.records[-1]["dev_loss"] == pytest.approx(num / den, rel=1e-5)
+    t.cleanup()
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+def test_cpt_trainer_with_clipping_matches_cpu_step_oracle(tmp_path, dtype, tol):
+    """BASELINE config C's route at test size: ``config_name=cpt`` (labels = tokens, TextCompletion batches of 16 rows), grad-accum 2,
+    global-norm clipping, three steps — per-step losses and the logged gradient norms against the CPU step oracle."""
+    from oracle import step_oracle
+    from oracle.llama_oracle import OracleCEWithChunkedOutputLoss, OracleLlama
+    from ssi.lr_schedule import get_cosine_schedule_with_warmup
+    model = SMALL if dtype == "fp32" else MFMA_SMALL
+    t = _trainer(tmp_path, "cpt", config_name="cpt", dtype=dtype, model=model, seq=128, overrides=[
+        "max_steps=3", "clip_grad_norm=0.05", "data.train.dataloader.batch_size=4", "data.train.shuffle=false", "lr_scheduler.num_warmup_steps=2",
+        "optimizer.lr=1e-3"])
+    assert t.cfg.config_name == "cpt" and t.cfg.clip_grad_norm == 0.05
+    sd0 = {k: v.detach().float().cpu().clone() for k, v in t.model.state_dict().items()}
+    batches = [{k: v.clone() for k, v in b.items()} for b in itertools.islice(iter(t.data_train), 6)]
+    assert all(bool(((b["labels"] == b["tokens"]) | (b["labels"] == -100)).all()) for b in batches)
+    assert int((batches[0]["labels"] != -100).sum()) > 0.9 * batches[0]["tokens"].numel()   # CPT: (nearly) every position is a target
+    t.train()
+    assert t.global_step == 3
+    ref = OracleLlama(**t._llama_config.parameters, rope_cache_len=512)
+    ref.load_state_dict(sd0)
+    ref.set_num_output_chunks(8)
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    sched = get_cosine_schedule_with_warmup(opt, num_warmup_steps=2, num_training_steps=3, num_cycles=0.5)
+    losses, norms = [], []
+    for w in (batches[0:2], batches[2:4], batches[4:6]):
+        lr, nt = 0.0, 0
+        for mb in w:
+            lb, n = step_oracle.train_step(ref, OracleCEWithChunkedOutputLoss(), mb)
+            lr, nt = lr + lb, nt + n
+        norms.append(step_oracle.optimizer_step(ref, opt, nt, clip_grad_norm=0.05, lr_scheduler=sched))
+        losses.append(lr / nt)
+    got_norms = [r["grad_norm"] for r in t.wandb_logger.records]
+    print("gpu", t._loss_log, got_norms, "\ncpu", losses, norms)
+    for a, b in zip(t._loss_log, losses):
+        assert abs(a - b) <= tol * abs(b)
+    for a, b in zip(got_norms, norms):
+        assert b > 0.05, "the test must actually clip"
+        assert abs(a - b) <= (1e-3 if dtype == "fp32" else 5e-2) * b
+    t.cleanup()
