@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define SSI_ABI_VERSION 2 /* 2: + ssi_attn_varlen_fwd/bwd(_rope), ssi_set_gemm_tile_order, NN form of ssi_gemm_swiglu_bwd */
+#define SSI_ABI_VERSION 3 /* 2: + ssi_attn_varlen_fwd/bwd(_rope), ssi_set_gemm_tile_order, NN form of ssi_gemm_swiglu_bwd
+                           * 3: ssi_ce_reduce takes `vocab` and reports out-of-range labels in out[3] */
 
 enum { SSI_F32 = 0, SSI_BF16 = 1 };
 enum { SSI_OK = 0, SSI_ERR_ARG = 1, SSI_ERR_UNSUPPORTED = 2, SSI_ERR_WORKSPACE = 3, SSI_ERR_HIP = 1000 /* + hipError_t */ };
@@ -153,8 +154,12 @@ int ssi_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, in
  * softmax(logits[r]) - onehot(label) (0 for ignored rows and for padding columns) — the unscaled d(sum NLL)/dlogits. */
 int ssi_ce_fwd(void* logits, int64_t ld, const int64_t* labels, int64_t rows, int64_t vocab, int64_t ignore_index,
                float* row_loss, float* row_lse, int write_grad, int dtype, void* stream);
-/* out[0] = sum(row_loss) / n_valid (NaN if n_valid == 0, as the reference), out[1] = sum(row_loss), out[2] = n_valid */
-int ssi_ce_reduce(const float* row_loss, const int64_t* labels, int64_t rows, int64_t ignore_index, float* out,
+/* bf16 rows of up to 196 608 columns are held in registers by one workgroup per CU: the log-sum-exp and the gradient come from ONE
+ * read of the row (2 passes over the logits, not 3).  A label that is neither `ignore_index` nor inside [0, vocab) gives a zero
+ * loss and a zero gradient row here and is COUNTED by ssi_ce_reduce (out[3]): the caller raises when it next reads back. */
+/* out[0] = sum(row_loss) / n_valid (NaN if n_valid == 0, as the reference), out[1] = sum(row_loss), out[2] = n_valid (labels that
+ * are not ignored and lie in [0, vocab) — the predicate ssi_ce_fwd uses), out[3] = number of out-of-range labels.  out: 4 floats. */
+int ssi_ce_reduce(const float* row_loss, const int64_t* labels, int64_t rows, int64_t vocab, int64_t ignore_index, float* out,
                   void* stream);
 
 /* ---- K14 count_token_types + valid-label count (ssi/train_utils.py:150-165, ssi/trainer.py:388,391) ---------------- */

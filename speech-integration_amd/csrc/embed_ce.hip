@@ -242,33 +242,180 @@ __global__ __launch_bounds__(512) void ce_fwd_kernel(T* __restrict__ logits, int
     }
 }
 
+// bf16 rows held in registers (the training step's form): one 1024-thread workgroup per CU walks rows; a row of NCH x 8192 logits
+// (NCH = 17: 139 264 >= 133 376) lives in NCH 16-byte registers per thread, so the log-sum-exp and the gradient both come from ONE
+// read of the row: 2 passes over the logits (read + write back = 8.7 GB at T = 16 384, V = 133 258) instead of the 3 of
+// ce_fwd_kernel above (13.1 GB).  A register's next-row load is issued as soon as its gradient has been stored, so the next row
+// streams in under the stores and the exps of the current one.  NCH = ceil(ld / 8192) exactly and ld - vocab < 8192: only the last
+// two chunks can hold columns that are not vocabulary.  Straight-line body (the only branches are workgroup-uniform and read-only
+// on the row registers): with per-chunk branches hipcc spills the row.
+template <int NCH, bool write_grad>
+__global__ __launch_bounds__(1024, 4) void ce_row_bf16_kernel(bf16_t* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
+                                                              int64_t rows, int64_t vocab, int64_t ignore_index,
+                                                              float* __restrict__ row_loss, float* __restrict__ row_lse) {
+    __shared__ float red[16];
+    constexpr float LOG2E = 1.44269504088896340736f;
+    constexpr int CHUNK = 8192;                      // columns per chunk: 1024 threads x 8 bf16
+    const int tid = threadIdx.x;
+    const int voff = tid * 16;                       // the one per-lane byte offset; the chunk rides in the scalar offset
+    const int col0 = tid * 8;                        // this lane's first column inside a chunk
+    const int row_bytes = (int)(ld * 2);             // buffer bound: loads beyond the row return 0, stores beyond it are dropped
+    const int vocab_i = (int)vocab;
+    u32x4 x[NCH];
+    auto is_valid = [&](int64_t label) { return label != ignore_index && label >= 0 && label < vocab; };
+    auto rsrc_of = [&](int64_t row) { return __builtin_amdgcn_make_buffer_rsrc(logits + row * ld, 0, row_bytes, 0x00020000u); };
+    auto lo = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
+    auto hi = [](unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); };
+    // the three passes each re-derive the fp32 values from the packed registers: without this opaque touch the compiler keeps all
+    // 8 x NCH converted floats alive across the passes and spills
+    auto opaque = [&]() {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) asm volatile("" : "+v"(x[c][d]));
+    };
+    int64_t row = blockIdx.x;
+    if (row >= rows) return;
+    {
+        const __amdgpu_buffer_rsrc_t r0 = rsrc_of(row);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) x[c] = __builtin_amdgcn_raw_buffer_load_b128(r0, voff, c * CHUNK * 2, 0);
+    }
+    for (; row < rows; row += gridDim.x) {
+        const int64_t next = row + gridDim.x;
+        const int64_t label = labels[row];
+        const bool valid = is_valid(label);
+        const __amdgpu_buffer_rsrc_t rs = rsrc_of(row);
+        // columns that are not vocabulary (the pad columns [vocab, ld), and beyond the row where the loads returned 0) become -inf
+        // once, in the registers: max, exp-sum and gradient (exp2(-inf) = 0) then need no column test at all
+#pragma unroll
+        for (int c = (NCH >= 2 ? NCH - 2 : 0); c < NCH; ++c) {
+            const int left = vocab_i - c * CHUNK - col0;  // real columns from this lane's first one on
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                if (2 * d >= left) x[c][d] = (x[c][d] & 0xffff0000u) | 0x0000ff80u;
+                if (2 * d + 1 >= left) x[c][d] = (x[c][d] & 0x0000ffffu) | 0xff800000u;
+            }
+        }
+        float nl = -INFINITY;  // ignored / out-of-range label: every exp2 below gives 0 -> zero gradient row
+        if (valid) {           // workgroup-uniform; reads the row registers only
+            float xl = 0.f;
+            if (tid == 0) xl = (float)logits[row * ld + label];  // before this row's gradient is written (program order of one thread)
+            float m = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) m = fmaxf(m, fmaxf(lo(x[c][d]), hi(x[c][d])));
+            const float gm = block_max(m, red);
+            opaque();
+            const float nm = -gm * LOG2E;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    s += __builtin_amdgcn_exp2f(fmaf(lo(x[c][d]), LOG2E, nm)) + __builtin_amdgcn_exp2f(fmaf(hi(x[c][d]), LOG2E, nm));
+            const float gs = block_sum(s, red);
+            const float lse = gm + logf(gs);
+            if (tid == 0) {
+                row_loss[row] = lse - xl;
+                if (row_lse) row_lse[row] = lse;
+            }
+            nl = -lse * LOG2E;
+        } else if (tid == 0) {
+            row_loss[row] = 0.f;
+            if (row_lse) row_lse[row] = 0.f;
+        }
+        opaque();
+        // ---- gradient softmax - onehot, written over the logits; each register then takes the next row's chunk (past the last row:
+        // this row again — a few wasted loads at the very end instead of a branch around every load)
+        const int hot = valid ? (int)label - col0 : -(1 << 30);  // the label's column relative to this lane's first column of chunk 0
+        const __amdgpu_buffer_rsrc_t rn = rsrc_of(next < rows ? next : row);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (write_grad) {
+                float g[8];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    g[2 * d] = __builtin_amdgcn_exp2f(fmaf(lo(x[c][d]), LOG2E, nl));
+                    g[2 * d + 1] = __builtin_amdgcn_exp2f(fmaf(hi(x[c][d]), LOG2E, nl));
+                }
+                const int h = hot - c * CHUNK;
+                if ((unsigned)h < 8u) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (e == h) g[e] -= 1.f;
+                }
+                bf16x8 ob;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)g[e];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), rs, voff, c * CHUNK * 2, 0);
+            }
+            x[c] = __builtin_amdgcn_raw_buffer_load_b128(rn, voff, c * CHUNK * 2, 0);
+            __builtin_amdgcn_sched_barrier(0);  // one chunk at a time: a hoisted next-row load would need a register of its own
+        }
+    }
+}
+
+static int ce_num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();  // thread-safe one-time initialisation (C++11 magic static)
+    return n;
+}
+
 extern "C" int ssi_ce_fwd(void* logits, int64_t ld, const int64_t* labels, int64_t rows, int64_t vocab,
                           int64_t ignore_index, float* row_loss, float* row_lse, int write_grad, int dtype, void* stream) {
     SSI_CHECK_ARG(logits && labels && row_loss && rows >= 0 && vocab > 0 && ld >= vocab && ld % 8 == 0);
     if (rows == 0) return SSI_OK;
+    const int64_t chunks = ssi_cdiv(ld, 8192);
+    const bool row_form = dtype == SSI_BF16 && ((uintptr_t)logits & 15) == 0 && ld - vocab < 8192 && ld * 2 < (1LL << 31) &&
+                          (chunks <= 4 || chunks == 8 || (chunks >= 16 && chunks <= 18));
+    if (row_form) {
+        const dim3 grid((unsigned)(rows < ce_num_cus() ? rows : ce_num_cus()));
+#define SSI_CE_ROW(N)                                                                                                                       \
+    case N:                                                                                                                                 \
+        if (write_grad) hipLaunchKernelGGL((ce_row_bf16_kernel<N, true>), grid, dim3(1024), 0, (hipStream_t)stream, (bf16_t*)logits, ld, labels, \
+                                           rows, vocab, ignore_index, row_loss, row_lse);                                                   \
+        else hipLaunchKernelGGL((ce_row_bf16_kernel<N, false>), grid, dim3(1024), 0, (hipStream_t)stream, (bf16_t*)logits, ld, labels, rows,     \
+                                vocab, ignore_index, row_loss, row_lse);                                                                    \
+        break
+        switch ((int)chunks) {
+            SSI_CE_ROW(1); SSI_CE_ROW(2); SSI_CE_ROW(3); SSI_CE_ROW(4); SSI_CE_ROW(8); SSI_CE_ROW(16); SSI_CE_ROW(17); SSI_CE_ROW(18);
+        }
+#undef SSI_CE_ROW
+        SSI_LAUNCH_CHECK();
+        return SSI_OK;
+    }
     SSI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(ce_fwd_kernel<T>, dim3((unsigned)rows), dim3(512), 0, (hipStream_t)stream,
                                                  (T*)logits, ld, labels, vocab, ignore_index, row_loss, row_lse, write_grad));
     SSI_LAUNCH_CHECK();
     return SSI_OK;
 }
 
+// The valid-label count uses the predicate of the row kernels (not ignored AND inside [0, vocab)); labels that are neither ignored
+// nor in range are counted in out[3] so that the caller can raise on its next host read-back (torch would device-assert).
 __global__ __launch_bounds__(1024) void ce_reduce_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ labels,
-                                                         int64_t rows, int64_t ignore_index, float* __restrict__ out) {
+                                                         int64_t rows, int64_t vocab, int64_t ignore_index, float* __restrict__ out) {
     __shared__ float red[16];
-    float s = 0.f, c = 0.f;
+    float s = 0.f, c = 0.f, bad = 0.f;
     for (int64_t r = threadIdx.x; r < rows; r += 1024) {
-        s += row_loss[r];
-        c += (labels[r] != ignore_index) ? 1.f : 0.f;
+        const int64_t l = labels[r];
+        const bool in_range = l >= 0 && l < vocab;
+        if (l != ignore_index && in_range) { s += row_loss[r]; c += 1.f; }
+        else if (l != ignore_index) bad += 1.f;
     }
     s = block_sum(s, red);
     c = block_sum(c, red);
-    if (threadIdx.x == 0) { out[0] = s / c; out[1] = s; out[2] = c; }
+    bad = block_sum(bad, red);
+    if (threadIdx.x == 0) { out[0] = s / c; out[1] = s; out[2] = c; out[3] = bad; }
 }
 
-extern "C" int ssi_ce_reduce(const float* row_loss, const int64_t* labels, int64_t rows, int64_t ignore_index, float* out,
-                             void* stream) {
-    SSI_CHECK_ARG(row_loss && labels && out && rows >= 0 && rows < (1LL << 24));
-    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, labels, rows, ignore_index, out);
+extern "C" int ssi_ce_reduce(const float* row_loss, const int64_t* labels, int64_t rows, int64_t vocab, int64_t ignore_index,
+                             float* out, void* stream) {
+    SSI_CHECK_ARG(row_loss && labels && out && rows >= 0 && rows < (1LL << 24) && vocab > 0);
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, labels, rows, vocab, ignore_index, out);
     SSI_LAUNCH_CHECK();
     return SSI_OK;
 }

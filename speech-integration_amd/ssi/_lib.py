@@ -20,7 +20,7 @@ SSI_F32, SSI_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_MFMA_WG8 = 0, 1, 2, 3
 TILES_STATIC, TILES_DYNAMIC = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # name -> (restype, argtypes); mirrors include/ssi_hip.h line by line
 _P = c_void_p
@@ -56,7 +56,7 @@ PROTOTYPES = {
                                     _P]),
     "ssi_transpose": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int, _P]),
     "ssi_ce_fwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, c_int, c_int, _P]),
-    "ssi_ce_reduce": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
+    "ssi_ce_reduce": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P]),
     "ssi_count_tokens": (c_int, [_P, _P, c_int64, _P, c_int, c_int64, c_int64, _P, _P]),
     "ssi_scale_inplace": (c_int, [_P, c_int64, c_float, _P, c_int, _P]),
     "ssi_sumsq_workspace_bytes": (c_int64, [c_int64]),

@@ -50,8 +50,8 @@ class _CrossEntropyFn(torch.autograd.Function):
         work[:, :vocab].copy_(logits)
         row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
         ops.ce_fwd(work, labels, vocab, ignore_index, row_loss, None, ctx.needs_input_grad[0])
-        out = torch.empty(3, dtype=torch.float32, device=logits.device)
-        ops.ce_reduce(row_loss, labels, ignore_index, out)
+        out = torch.empty(4, dtype=torch.float32, device=logits.device)
+        ops.ce_reduce(row_loss, labels, vocab, ignore_index, out)
         ctx.vocab = vocab
         ctx.save_for_backward(work, out)
         return out[0].clone()

@@ -219,6 +219,7 @@ class HipLlamaDecoder(nn.Module):
         self._fwd_generation = 0
         self.pending_grad_scale: Optional[Tensor] = None  # lazy scale_grads (device fp32 scalar), consumed by the optimizer
         self._grads_dirty = False
+        self.label_errors: Optional[Tensor] = None        # device count of out-of-range labels seen by the last fused loss
         self.grad_sync = None                             # optional ssi.distributed.GradSync
         self.sync_this_backward = False
 
@@ -308,7 +309,7 @@ class HipLlamaDecoder(nn.Module):
 
     # ---- forward: decoder stack --------------------------------------------------------------------------------------
     @staticmethod
-    def _document_ranges(input_pos: Tensor) -> tuple[Tensor, Tensor, Tensor]:
+    def _document_ranges(input_pos: Tensor, max_pos: Optional[int] = None) -> tuple[Tensor, Tensor, Tensor]:
         """Packed rows (torchtune ``PackedDataset``: ``input_pos`` restarts at 0 with every document of a row) -> int32 [B*S]
         (positions, doc_start, doc_end): a query attends to the keys doc_start <= key <= query of its own row, which is the
         block-causal mask ``padded_collate_packed`` builds from ``seq_lens``.  The padding tail of a pack continues the last
@@ -322,7 +323,7 @@ class HipLlamaDecoder(nn.Module):
         nxt = torch.cat([nxt[:, 1:], torch.full_like(nxt[:, :1], S)], dim=1)  # first document start strictly after s
         doc_end = nxt.flip(1).cummin(dim=1).values.flip(1)
         as32 = lambda t: t.to(torch.int32).reshape(-1).contiguous()  # noqa: E731
-        return as32(input_pos), as32(doc_start), as32(doc_end)
+        return as32(input_pos if max_pos is None else input_pos.clamp(max=max_pos)), as32(doc_start), as32(doc_end)
 
     def _forward_hidden(self, tokens: Tensor, save: bool, input_pos: Optional[Tensor] = None) -> Tensor:
         B, S = tokens.shape
@@ -330,16 +331,19 @@ class HipLlamaDecoder(nn.Module):
         if input_pos is not None:
             if input_pos.shape != tokens.shape:
                 raise ValueError("input_pos must have the shape of tokens")
-            if int(input_pos.max()) >= self._rope.shape[0]:
+            if not input_pos.is_cuda and int(input_pos.max()) >= self._rope.shape[0]:  # host tensor: checking costs no device sync
                 raise ValueError("input_pos exceeds the RoPE cache")
-            pos, ds, de = self._document_ranges(input_pos.to(tokens.device))
+            # device tensor: no blocking read-back in the step; positions are clamped to the cache instead (the data layer bounds
+            # them by tokenizer.max_seq_len <= rope cache, ssi/data/packed.py), so the kernels never index past the table
+            pos, ds, de = self._document_ranges(input_pos.to(tokens.device), self._rope.shape[0] - 1)
         T, D, I = B * S, self.embed_dim, self.intermediate_dim
         H, KV, hd, dt, A = self.num_heads, self.num_kv_heads, self.head_dim, self.dtype, self._arena
         if S > self._rope.shape[0]:
             raise ValueError(f"sequence length {S} exceeds the RoPE cache ({self._rope.shape[0]})")
         tok = tokens.reshape(-1).contiguous()
         L = self.num_layers
-        h = A.get("h0", (T, D), dt)
+        # a forward that saves nothing (eval, no_grad) writes ".x" buffers only: it may run between a training forward and its backward
+        h = A.get("h0" if save else "h0.x", (T, D), dt)
         ops.embed_fwd(tok, self._view("emb"), h, self.vocab_size)
         for l in range(L):
             sfx = f"{l}" if save else "x"
@@ -363,8 +367,8 @@ class HipLlamaDecoder(nn.Module):
             hnext = A.get(hn_name, (T, D), dt)
             ops.gemm(GEMM_NT, act, self._view(f"L{l}.w2"), hnext, residual=hmid)
             h = hnext
-        hn = A.get("hn", (T, D), dt)
-        rstdf = A.get("rstdf", (T,), torch.float32)
+        hn = A.get("hn" if save else "hn.x", (T, D), dt)
+        rstdf = A.get("rstdf" if save else "rstdf.x", (T,), torch.float32)
         ops.rmsnorm_fwd(h, self.norm.scale, hn, rstdf, self.norm_eps)
         if save:
             self._fwd_generation += 1
@@ -453,9 +457,14 @@ class HipLlamaDecoder(nn.Module):
         self.attach_grads()
 
     # ---- tied LM head ------------------------------------------------------------------------------------------------
-    def _head_logits(self, hn: Tensor) -> Tensor:
+    def _head_logits(self, hn: Tensor, arena_name: Optional[str] = None) -> Tensor:
+        """logits [T, vocab_pad] = hn E^T.  Callers of the public ``forward`` get a FRESH tensor (as torchtune returns): logits kept
+        from one batch must survive the next forward.  Only the fused loss passes an arena name (its buffer never leaves the model)."""
         T = hn.shape[0]
-        logits = self._arena.get("logits", (T, self.vocab_pad), self.dtype)
+        if arena_name is None:
+            logits = torch.empty((T, self.vocab_pad), dtype=self.dtype, device=self.device)
+        else:
+            logits = self._arena.get(arena_name, (T, self.vocab_pad), self.dtype)
         ops.gemm(GEMM_NT, hn, self._view("emb"), logits)
         return logits
 
@@ -539,11 +548,12 @@ class HipLlamaDecoder(nn.Module):
 
     def _ce_forward(self, hn: Tensor, labels: Tensor, ignore_index: int, write_grad: bool) -> tuple[Tensor, Tensor, Tensor]:
         T = hn.shape[0]
-        logits = self._head_logits(hn)
-        row_loss = self._arena.get("row_loss", (T,), torch.float32)
+        logits = self._head_logits(hn, "logits" if write_grad else "logits.x")
+        row_loss = self._arena.get("row_loss" if write_grad else "row_loss.x", (T,), torch.float32)
         ops.ce_fwd(logits, labels, self.vocab_size, ignore_index, row_loss, None, write_grad)
-        out = torch.empty(3, dtype=torch.float32, device=self.device)
-        ops.ce_reduce(row_loss, labels, ignore_index, out)
+        out = torch.empty(4, dtype=torch.float32, device=self.device)
+        ops.ce_reduce(row_loss, labels, self.vocab_size, ignore_index, out)
+        self.label_errors = out[3]  # device scalar: labels outside [0, vocab); the trainer folds it into its one read-back and raises
         return out[0], out, logits
 
 
@@ -594,6 +604,9 @@ class _FusedLossFn(torch.autograd.Function):
     def backward(ctx, grad_out: Tensor):
         hn, stats, dlogits = ctx.saved_tensors
         m = ctx.model
+        if m._saved is None or m._saved["gen"] != ctx.gen:  # checked BEFORE the head backward touches the gradient buffer
+            raise RuntimeError("HipLlamaDecoder: backward called for a forward whose activations were overwritten; "
+                               "run backward before the next training forward")
         # d loss / d logits = (softmax - onehot) / n_valid ; the 1/n_valid and the upstream scalar ride in alpha_dev
         alpha = (grad_out.to(torch.float32).reshape(1) / stats[2:3]).contiguous()
         d_hn = m._head_backward(dlogits, hn, alpha)

@@ -246,9 +246,10 @@ def ce_fwd(logits: Tensor, labels: Tensor, vocab: int, ignore_index: int, row_lo
                                  ptr(row_lse), int(write_grad), dtype_code(logits.dtype), stream_ptr()), "ssi_ce_fwd")
 
 
-def ce_reduce(row_loss: Tensor, labels: Tensor, ignore_index: int, out: Tensor) -> None:
-    assert out.dtype == torch.float32 and out.numel() >= 3 and labels.is_contiguous()
-    check(_lib.load().ssi_ce_reduce(ptr(row_loss), ptr(labels), labels.numel(), ignore_index, ptr(out), stream_ptr()),
+def ce_reduce(row_loss: Tensor, labels: Tensor, vocab: int, ignore_index: int, out: Tensor) -> None:
+    """out[0] mean NLL over valid labels, out[1] sum, out[2] valid count, out[3] labels that are neither ignored nor in [0, vocab)."""
+    assert out.dtype == torch.float32 and out.numel() >= 4 and labels.is_contiguous()
+    check(_lib.load().ssi_ce_reduce(ptr(row_loss), ptr(labels), labels.numel(), vocab, ignore_index, ptr(out), stream_ptr()),
           "ssi_ce_reduce")
 
 

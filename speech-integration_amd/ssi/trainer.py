@@ -344,10 +344,18 @@ class Trainer:
         loss_batch = compute_loss(batch, self.model, self.loss_fn) * n_valid  # mean over SHIFTED x UNSHIFTED count
         loss_batch.backward()
         if on_gpu:
-            host = torch.cat((counts_dev.to(torch.float64), loss_batch.detach().to(torch.float64).reshape(1))).tolist()
+            bad_labels = getattr(self.model, "label_errors", None)
+            bad_labels = bad_labels.detach().to(torch.float64).reshape(1) if bad_labels is not None else torch.zeros(1, dtype=torch.float64, device=tokens.device)
+            host = torch.cat((counts_dev.to(torch.float64), loss_batch.detach().to(torch.float64).reshape(1), bad_labels)).tolist()
             names = list(self.token_type_ranges) + ["total"]
             counts_host = {tt: int(c) for tt, c in zip(names, host)}
-            num_tokens_iter, loss_value = int(host[len(names)]), float(host[-1])
+            num_tokens_iter, loss_value = int(host[len(names)]), float(host[-2])
+            # ids outside the vocabulary: torch's embedding / cross_entropy would device-assert (the HIP kernels write zeros and count);
+            # the token-type ranges partition [0, V), so a token outside them shows up as a short sum — both read from this one copy
+            if int(host[-1]) != 0:
+                raise IndexError(f"{int(host[-1])} label(s) outside [0, vocab_size) in this micro-batch")
+            if sum(counts_host[tt] for tt in self.token_type_ranges) != tokens.numel():
+                raise IndexError("token id(s) outside [0, vocab_size) in this micro-batch")
         else:
             num_tokens_iter, loss_value = int(n_valid.item()), float(loss_batch.item())
         for tt, c in counts_host.items():

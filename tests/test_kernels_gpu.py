@@ -134,7 +134,7 @@ def test_embedding_gather_and_deterministic_scatter(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("vocab,ld", [(515, 520), (133_258, 133_376)])
+@pytest.mark.parametrize("vocab,ld", [(515, 520), (133_258, 133_376), (136_450, 136_704), (130_306, 130_560), (20_000, 20_480)])
 def test_cross_entropy_rows_reduce_and_grad(ops, dtype, vocab, ld):
     rows = 24
     logits = rnd(rows, ld, dtype=dtype, seed=12, scale=3.0)
@@ -153,10 +153,10 @@ def test_cross_entropy_rows_reduce_and_grad(ops, dtype, vocab, ld):
     assert torch.equal(work.cpu(), logits), "write_grad=False must leave the logits untouched"
     torch.testing.assert_close(row_loss.cpu(), nll.detach(), rtol=1e-5, atol=2e-5)
     torch.testing.assert_close(row_lse.cpu()[labels != -100], torch.logsumexp(lr.detach(), -1)[labels != -100], rtol=1e-6, atol=1e-5)
-    out = torch.empty(3, dtype=torch.float32, device=DEV)
-    ops.ce_reduce(row_loss, labels.to(DEV), -100, out)
+    out = torch.empty(4, dtype=torch.float32, device=DEV)
+    ops.ce_reduce(row_loss, labels.to(DEV), vocab, -100, out)
     n_valid = int((labels != -100).sum())
-    assert out.cpu()[2].item() == n_valid
+    assert out.cpu()[2].item() == n_valid and out.cpu()[3].item() == 0
     assert out.cpu()[0].item() == pytest.approx(float(nll.sum()) / n_valid, rel=1e-5)
     ops.ce_fwd(work, labels.to(DEV), vocab, -100, row_loss, None, True)
     grad = work.cpu().float()
@@ -165,8 +165,48 @@ def test_cross_entropy_rows_reduce_and_grad(ops, dtype, vocab, ld):
     # all rows ignored -> 0/0 = NaN like the reference
     allign = torch.full((rows,), -100, dtype=torch.int64, device=DEV)
     ops.ce_fwd(logits.to(DEV), allign, vocab, -100, row_loss, None, False)
-    ops.ce_reduce(row_loss, allign, -100, out)
+    ops.ce_reduce(row_loss, allign, vocab, -100, out)
     assert math.isnan(out.cpu()[0].item()) and out.cpu()[2].item() == 0
+    # a label outside [0, vocab) (torch would device-assert): zero loss, zero gradient row, NOT counted as valid, reported in out[3]
+    bad = labels.clone()
+    bad[0], bad[7] = vocab, -5
+    work = logits.to(DEV)
+    ops.ce_fwd(work, bad.to(DEV), vocab, -100, row_loss, None, True)
+    ops.ce_reduce(row_loss, bad.to(DEV), vocab, -100, out)
+    o = out.cpu()
+    ok_rows = (bad != -100) & (bad >= 0) & (bad < vocab)
+    assert o[3].item() == 2 and o[2].item() == int(ok_rows.sum())
+    assert o[1].item() == pytest.approx(float(nll.detach()[ok_rows].sum()), rel=1e-5)
+    assert (work.cpu().float()[0] == 0).all() and (work.cpu().float()[7] == 0).all() and row_loss.cpu()[0] == 0
+
+
+def test_cross_entropy_register_resident_rows_many_rows_per_workgroup(ops):
+    """More rows than workgroups (each of the 256 walks several rows, the next row's loads issued from inside the gradient pass),
+    ignored rows in between, against fp32 torch on the CPU and against the 3-pass kernel's fp32 instance."""
+    rows, vocab, ld = 700, 9000, 9216
+    logits = rnd(rows, ld, dtype=torch.bfloat16, seed=120, scale=4.0)
+    labels = torch.randint(0, vocab, (rows,), generator=torch.Generator().manual_seed(121))
+    labels[::7] = -100
+    labels[300:330] = -100
+    lr = logits[:, :vocab].float().clone().requires_grad_(True)
+    nll = F.cross_entropy(lr, labels, ignore_index=-100, reduction="none")
+    nll.sum().backward()
+    work = logits.to(DEV)
+    row_loss = torch.empty(rows, dtype=torch.float32, device=DEV)
+    row_lse = torch.empty(rows, dtype=torch.float32, device=DEV)
+    ops.ce_fwd(work, labels.to(DEV), vocab, -100, row_loss, row_lse, True)
+    torch.testing.assert_close(row_loss.cpu(), nll.detach(), rtol=1e-5, atol=2e-5)
+    grad = work.cpu().float()
+    torch.testing.assert_close(grad[:, :vocab], lr.grad, rtol=1e-2, atol=4e-3)
+    assert (grad[:, vocab:] == 0).all() and (grad[labels == -100] == 0).all()
+    work2 = logits.to(DEV)
+    ops.ce_fwd(work2, labels.to(DEV), vocab, -100, row_loss, None, True)
+    assert torch.equal(work, work2), "not bitwise reproducible"
+    f32 = logits.float().to(DEV)                       # the 3-pass kernel (fp32 instance) on the same values
+    rl32 = torch.empty(rows, dtype=torch.float32, device=DEV)
+    ops.ce_fwd(f32, labels.to(DEV), vocab, -100, rl32, None, True)
+    torch.testing.assert_close(row_loss.cpu(), rl32.cpu(), rtol=1e-5, atol=2e-5)
+    assert float((f32.cpu() - grad).abs().max()) <= 4e-3
 
 
 def test_count_tokens_matches_reference_counts(ops):

@@ -149,6 +149,40 @@ def test_backward_after_overwritten_forward_fails_loudly():
         l1.backward()
 
 
+def test_returned_logits_are_not_overwritten_and_eval_between_forward_and_backward_is_harmless():
+    """torchtune returns fresh logits: tensors kept from one batch survive the next forward.  An eval / no_grad forward (dev loss,
+    logit inspection) between a training forward and its backward must leave that backward's gradients untouched."""
+    from ssi.loss import CEWithChunkedOutputLoss, compute_loss
+    model, batch, params, _ = _build("small", torch.float32)
+    dbatch = _to_dev(batch)
+    other = {"tokens": (dbatch["tokens"] + 3) % params["vocab_size"], "labels": dbatch["labels"]}
+    model.eval()
+    with torch.no_grad():
+        first = model(tokens=dbatch["tokens"])
+        keep = [c.clone() for c in first]
+        second = model(tokens=other["tokens"])
+        model.set_num_output_chunks(0)
+        full = model(tokens=dbatch["tokens"])
+        model.set_num_output_chunks(8)
+    assert all(torch.equal(a, b) for a, b in zip(first, keep)), "logits of the first batch were overwritten by the second forward"
+    assert not torch.equal(first[0], second[0])
+    assert torch.equal(torch.cat(first, dim=1).float(), full)
+    loss_fn = CEWithChunkedOutputLoss()
+    model.train()
+    model.zero_grad()
+    compute_loss(dbatch, model, loss_fn).backward()
+    want = model._flat_grad.clone()
+    model.zero_grad()
+    loss = compute_loss(dbatch, model, loss_fn)
+    model.eval()
+    with torch.inference_mode():                       # a dev-loss pass and a logits call squeezed in before backward
+        compute_loss(other, model, loss_fn)
+        model(tokens=other["tokens"])
+    model.train()
+    loss.backward()
+    assert torch.equal(model._flat_grad, want), "an eval forward between forward and backward changed the gradients"
+
+
 @pytest.mark.parametrize("dtype_name,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
 def test_trainer_three_steps_match_cpu_step_oracle(tmp_path, dtype_name, tol):
     """End to end through Trainer.setup()/train() with synthetic MLS-shaped data, grad-accum 2, vs the CPU step oracle."""
