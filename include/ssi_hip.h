@@ -9,8 +9,14 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless named host_*; the caller (PyTorch's allocator) owns all buffers,
  *     including workspaces; the library allocates nothing persistent and never synchronises the device.
- *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered; entries are re-entrant and thread-safe
- *     (autograd runs backward on another host thread).
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered.  Compute entries keep no per-call host state and may
+ *     be called from any host thread (autograd runs backward on another thread than forward); their one-time set-up (LDS size
+ *     attribute, CU count) is done under C++ thread-safe static initialisation.
+ *   - PROCESS-GLOBAL state, stated here because it is not per call: (1) ssi_set_impl and (2) ssi_set_gemm_tile_order are switches
+ *     for the whole process (atomics; meant to be set once at start-up — tests, A/B runs, the data-parallel trainer — not flipped
+ *     while another thread is launching); (3) with SSI_TILES_DYNAMIC the persistent GEMM draws tiles from 16 scheduler slots in
+ *     device memory handed out round-robin per launch, shared by all streams of the process: more than 16 persistent GEMMs in
+ *     flight at once on one device would share a slot (the trainer has at most two).
  *   - return 0 on success; SSI_ERR_* otherwise (never throws).  ssi_last_error() gives a thread-local message.
  *   - dtype: SSI_F32 or SSI_BF16 selects the storage type of activations/weights; reductions, softmax, norms and
  *     accumulators are always fp32 (the reference's rounding points).

@@ -1,6 +1,6 @@
 // ABI version + thread-local error text for libssi_hip.so.
 #include <stdarg.h>
-#include "common.cuh"
+#include "common_hip.h"
 
 static thread_local char g_err[512] = "";
 

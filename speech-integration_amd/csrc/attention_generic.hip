@@ -6,7 +6,7 @@
 // Packed rows: doc_start[b*S + s] / doc_end[b*S + s] = first position / one past the last position of
 // the document that holds position s; a query then sees the keys doc_start <= j <= i only (torchtune's block-causal mask of
 // `padded_collate_packed`), a key is seen by the queries j <= i < doc_end.
-#include "common.cuh"
+#include "common_hip.h"
 
 int ssi_get_impl();
 bool ssi_attn_mfma_supported(int64_t ld, int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype);

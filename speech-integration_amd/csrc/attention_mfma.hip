@@ -15,7 +15,7 @@
 // group).  No atomics anywhere: dQ gets its own pass (recomputing S and dP) so every output has exactly one writer and
 // results are bitwise reproducible.
 #include <type_traits>
-#include "common.cuh"
+#include "common_hip.h"
 
 #ifndef DKV_RING
 #define DKV_RING 6

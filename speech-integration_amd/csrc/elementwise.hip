@@ -1,7 +1,7 @@
 // Bandwidth-bound kernels of the training step: RMSNorm, RoPE, SwiGLU, token counting, grad scaling, sum of squares,
 // AdamW.  All are HBM-roofline kernels: 16-byte per-lane accesses, one wave (64 lanes) per row for the row reductions,
 // shuffles for the reductions, fp32 math with the reference's rounding points.
-#include "common.cuh"
+#include "common_hip.h"
 
 // =====================================================================================================================
 // K2 RMSNorm forward: one wave per row (torchtune.modules.RMSNorm.forward)

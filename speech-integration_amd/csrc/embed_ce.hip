@@ -1,5 +1,5 @@
 // K1 embedding gather / deterministic scatter-add, and K9 cross-entropy over the DSU-extended vocabulary.
-#include "common.cuh"
+#include "common_hip.h"
 
 // =====================================================================================================================
 // K1 forward: out[t,:] = table[tokens[t],:]   (coalesced 16-B row copies; one block of 256 lanes per 4 KiB of row)

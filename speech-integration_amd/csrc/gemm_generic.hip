@@ -1,7 +1,8 @@
 // Generic GEMM: any shape, fp32 or bf16 storage, fp32 accumulate on the vector ALUs.  This is the fp32 parity path
 // (dtype=fp32 is a supported reference config, /root/reference/ssi/constants.py:25) and the fallback for shapes the
 // MFMA kernel (gemm_mfma.hip) does not take.  64x64 output tile per 256-thread block, 4x4 outputs per thread, BK=16.
-#include "common.cuh"
+#include "common_hip.h"
+#include <atomic>
 
 int ssi_gemm_mfma_bf16(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                        int64_t ldb, void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev,
@@ -13,13 +14,13 @@ int ssi_gemm_mfma_bf16_splitk(int layout, int64_t M, int64_t N, int64_t K, const
                               int64_t ldb, void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev,
                               int accumulate, int splits, float* slabs, void* stream);
 
-static int g_impl = SSI_IMPL_AUTO;
+// process-wide switch (tests, A/B runs): atomic so that the forward thread and autograd's backward thread never race on it
+static std::atomic<int> g_impl{SSI_IMPL_AUTO};
 extern "C" int ssi_set_impl(int impl) {
-    const int prev = g_impl;
-    if (impl >= SSI_IMPL_AUTO && impl <= SSI_IMPL_MFMA_WG8) g_impl = impl;
-    return prev;
+    if (impl >= SSI_IMPL_AUTO && impl <= SSI_IMPL_MFMA_WG8) return g_impl.exchange(impl, std::memory_order_relaxed);
+    return g_impl.load(std::memory_order_relaxed);
 }
-int ssi_get_impl() { return g_impl; }
+int ssi_get_impl() { return g_impl.load(std::memory_order_relaxed); }
 
 void ssi_gemm_mfma_set_dynamic_tiles(int on);
 extern "C" int ssi_set_gemm_tile_order(int mode) {

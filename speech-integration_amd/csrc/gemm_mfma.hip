@@ -17,7 +17,7 @@
 //       columns; they are scaled, rounded to bf16, staged through LDS and written as full 128-B row segments, adding
 //       the residual / previous C in the same pass (same rounding points as F.linear followed by `+`).
 // Workgroup -> tile map: XCD-aware (consecutive tiles of a group share A rows / B columns inside one XCD's L2).
-#include "common.cuh"
+#include "common_hip.h"
 #include <atomic>
 #include <type_traits>
 
@@ -449,12 +449,9 @@ int launch(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, cons
            int64_t ldc, const void* R, float alpha, const float* alpha_dev, int accumulate, hipStream_t st,
            int splits = 1, float* slabs = nullptr, EpiArgs ea = EpiArgs{nullptr, 0, nullptr, 0, 0}) {
     auto kern = gemm_mfma_kernel<A_COL, B_COL, SPLITK, EPI>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) { ssi_set_error("gemm_mfma: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return SSI_ERR_HIP + (int)e; }
-        attr_set = true;
-    }
+    // once per instantiation, whichever host thread gets here first (forward and autograd's backward thread both launch GEMMs)
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr_rc != hipSuccess) { ssi_set_error("gemm_mfma: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(attr_rc)); return SSI_ERR_HIP + (int)attr_rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n), (unsigned)splits), dim3(NTHREADS), LDS_BYTES, st, tiles_m,
                        tiles_n, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (const bf16_t*)R, alpha,
                        alpha_dev, accumulate, slabs, ea);
@@ -1061,17 +1058,15 @@ int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, 
                const void* R, float alpha, const float* alpha_dev, hipStream_t st, EpiArgs ea = EpiArgs{nullptr, 0, nullptr, 0, 0},
                int splits = 1, float* slabs = nullptr) {
     auto kern = gemm_nt4_kernel<A_COL, B_COL, EPI, PREV, SPLITK>;
-    static bool attr_set = false;  // per instantiation
-    static int num_cu = 256;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NT4_LDS_BYTES);
-        if (e != hipSuccess) { ssi_set_error("gemm_nt4: cannot reserve %d B of LDS: %s", NT4_LDS_BYTES, hipGetErrorString(e)); return SSI_ERR_HIP + (int)e; }
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            num_cu = prop.multiProcessorCount;
-        attr_set = true;
-    }
+    // one-time set-up per instantiation as C++11 thread-safe statics: the forward thread and autograd's backward thread may both be the
+    // first to launch a given form
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NT4_LDS_BYTES);
+    if (attr_rc != hipSuccess) { ssi_set_error("gemm_nt4: cannot reserve %d B of LDS: %s", NT4_LDS_BYTES, hipGetErrorString(attr_rc)); return SSI_ERR_HIP + (int)attr_rc; }
+    static const int num_cu = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
     const int ntiles = tiles_m * tiles_n * (SPLITK ? splits : 1);
     int grid = ntiles < num_cu ? ntiles : num_cu;
     const int slot = g_nt4_dynamic.load(std::memory_order_relaxed) ? (int)(nt4_next_slot() & 15) : -1;  // consecutive launches: different slots

@@ -35,80 +35,80 @@ def _missing_keys(cfg) -> set:
 
 
 def resolve_n_dsus(cfg) -> None:
-    """``speech.n_dsus`` <- ``data.n_dsus`` unless set explicitly (``train_utils.py:37-59``)."""
+    """Settle ``speech.n_dsus`` before anything reads it: a value given on the command line stands, otherwise the data config's
+    ``n_dsus`` (every ``conf/data/*`` child names its tokenizer's codebook size) is copied in.  Behaviour of the reference's
+    helper of the same name (``train_utils.py:37-59``)."""
     if cfg.speech.n_dsus is not None:
         return
-    data_n_dsus = cfg.data.get("n_dsus") if cfg.get("data") is not None else None
-    if data_n_dsus is not None:
-        cfg.speech.n_dsus = data_n_dsus
-        LOGGER.info(f"Auto-resolved speech.n_dsus={data_n_dsus} from data config")
-    else:
-        raise ValueError("speech.n_dsus must be set either via CLI (speech.n_dsus=5000) or "
-                         "by using a data config that specifies n_dsus.")
+    data_node = cfg.get("data")
+    from_data = data_node.get("n_dsus") if data_node is not None else None
+    if from_data is None:
+        raise ValueError("speech.n_dsus is unset and the data config names no n_dsus: pass speech.n_dsus=<codebook size> or pick a "
+                         "data config that sets n_dsus")
+    cfg.speech.n_dsus = from_data
+    LOGGER.info(f"speech.n_dsus={from_data} (taken from the data config)")
+
+
+_POSITIVE_INT_FIELDS = ("gradient_accumulation_steps", "max_steps", "log_interval", "eval_steps", "save_steps")
 
 
 def validate_train_cfg(cfg) -> None:
+    """Refuse a run config the trainer cannot execute; every problem is a ``ValueError`` naming the field."""
     if cfg.speech.n_dsus is None:
-        raise ValueError("speech.n_dsus is still null at validation time. Call resolve_n_dsus(cfg) before validate_train_cfg().")
+        raise ValueError("speech.n_dsus is null: call resolve_n_dsus(cfg) before validate_train_cfg(cfg)")
     if PRECISION_STR_TO_DTYPE.get(cfg.dtype) not in SUPPORTED_DTYPES:
-        raise ValueError(f"Unsupported dtype: {cfg.dtype}. Supported dtypes: {SUPPORTED_DTYPES}")
-    missing_keys = _missing_keys(cfg)
-    if missing_keys:
-        raise ValueError(f"Missing keys in config: {missing_keys}")
-    for field in ("gradient_accumulation_steps", "max_steps", "log_interval", "eval_steps", "save_steps"):
-        if cfg.get(field, 0) <= 0:
-            raise ValueError(f"Config field '{field}' must be a positive integer, got: {cfg.get(field)}")
-    if cfg.save_steps % cfg.eval_steps != 0:
-        raise ValueError(f"save_steps ({cfg.save_steps}) must be a multiple of eval_steps ({cfg.eval_steps})")
+        raise ValueError(f"dtype {cfg.dtype!r} is not supported (supported: {SUPPORTED_DTYPES})")
+    unset = _missing_keys(cfg)
+    if unset:
+        raise ValueError(f"mandatory config values are missing (???): {sorted(unset)}")
+    for name in _POSITIVE_INT_FIELDS:
+        value = cfg.get(name, 0)
+        if value <= 0:
+            raise ValueError(f"config field '{name}' must be a positive integer, got {value!r}")
+    if cfg.save_steps % cfg.eval_steps:
+        raise ValueError(f"save_steps ({cfg.save_steps}) must be a multiple of eval_steps ({cfg.eval_steps}): a checkpoint is "
+                         "written only at steps that also evaluate")
+
+
+# training_state.pt (schema v1): key in the file -> name under which the trainer consumes it
+_RESUME_FIELDS = {GLOBAL_STEP_KEY: "global_step", OPTIMIZER_KEY: "optimizer_state", LR_SCHEDULER_KEY: "lr_scheduler_state",
+                  RNG_KEY: "rng_state", TRAINING_HPARAMS_KEY: "training_hparams", CONSUMED_SAMPLES_KEY: "consumed_samples",
+                  CUMULATIVE_METRICS_KEY: "cumulative_metrics"}
 
 
 def resume_training_state(ckpt_dict: dict[str, Any]) -> dict[str, Any]:
-    """Extract and validate resume state from a schema-v1 checkpoint dict (``train_utils.py:84-107``)."""
-    if CHECKPOINT_VERSION_KEY not in ckpt_dict:
-        raise ValueError("Checkpoint predates the versioned schema (no 'checkpoint_version' key). "
-                         "Legacy checkpoints are not supported. Start a fresh training run.")
-    if ckpt_dict[CHECKPOINT_VERSION_KEY] != CHECKPOINT_VERSION:
-        raise ValueError(f"Checkpoint version mismatch: checkpoint has version {ckpt_dict[CHECKPOINT_VERSION_KEY]}, "
-                         f"but this code expects version {CHECKPOINT_VERSION}.")
+    """Check a loaded ``training_state.pt`` (schema version, seed) and hand its parts to the trainer under the names it uses."""
+    version = ckpt_dict.get(CHECKPOINT_VERSION_KEY)
+    if version is None:
+        raise ValueError(f"training state has no '{CHECKPOINT_VERSION_KEY}': it predates the versioned schema and cannot be resumed")
+    if version != CHECKPOINT_VERSION:
+        raise ValueError(f"training state is schema version {version}, this code reads version {CHECKPOINT_VERSION}")
     if ckpt_dict[SEED_KEY] != SEED:
-        raise ValueError(f"Seed mismatch: config={SEED}, checkpoint={ckpt_dict[SEED_KEY]}")
-    return {
-        "global_step": ckpt_dict[GLOBAL_STEP_KEY],
-        "optimizer_state": ckpt_dict[OPTIMIZER_KEY],
-        "lr_scheduler_state": ckpt_dict[LR_SCHEDULER_KEY],
-        "rng_state": ckpt_dict[RNG_KEY],
-        "training_hparams": ckpt_dict[TRAINING_HPARAMS_KEY],
-        "consumed_samples": ckpt_dict[CONSUMED_SAMPLES_KEY],
-        "cumulative_metrics": ckpt_dict[CUMULATIVE_METRICS_KEY],
-    }
+        raise ValueError(f"training state was written with seed {ckpt_dict[SEED_KEY]}, this run uses seed {SEED}")
+    return {name: ckpt_dict[key] for key, name in _RESUME_FIELDS.items()}
+
+
+_DATA_POSITION_HPARAMS = ("batch_size", "gradient_accumulation_steps", "world_size", "steps_per_epoch")
 
 
 def validate_resume_hparams(ckpt_hparams: dict[str, Any], current_hparams: dict[str, Any], force_resume: bool = False) -> None:
-    for key in ("batch_size", "gradient_accumulation_steps", "world_size", "steps_per_epoch"):
-        if key in ckpt_hparams and ckpt_hparams[key] != current_hparams[key]:
-            msg = (f"Training hparam mismatch on resume for '{key}': checkpoint={ckpt_hparams[key]}, "
-                   f"current={current_hparams[key]}. This breaks the step-to-data-position mapping.")
-            if force_resume:
-                LOGGER.warning(msg)
-            else:
-                raise ValueError(msg)
+    """``global_step`` maps to a position in the data only while these four values stay what they were when the checkpoint was
+    written; any change is an error unless ``force_resume`` (then a warning)."""
+    changed = [f"'{k}': checkpoint={ckpt_hparams[k]}, current={current_hparams[k]}" for k in _DATA_POSITION_HPARAMS
+               if k in ckpt_hparams and ckpt_hparams[k] != current_hparams[k]]
+    if not changed:
+        return
+    msg = "training hparams changed since the checkpoint (" + "; ".join(changed) + "): the step-to-data-position mapping no longer holds"
+    if not force_resume:
+        raise ValueError(msg)
+    LOGGER.warning(msg)
 
 
 def get_token_type_ranges(llama_config: ConfigLlama3_2) -> dict[str, tuple[int, int]]:
-    """Inclusive id ranges per token type; layout ``[text | dsu | modality(2) | special_text]``
-    (``train_utils.py:129-147``, ``ssi/extend_llama3_2/__init__.py:100``)."""
-    base = llama_config._base_vocab_size_txt
-    ranges: dict[str, tuple[int, int]] = {"text": (0, base - 1), "dsu": (base, base + llama_config.n_dsus - 1)}
-    offset = base + llama_config.n_dsus
-    if llama_config.modality_tokens:
-        ranges["modality"] = (offset, offset + 1)
-        offset += 2
-    ranges["special_text"] = (offset, offset + llama_config._n_special_txt - 1)
-    offset += llama_config._n_special_txt
-    if offset != llama_config.vocab_size:
-        raise ValueError(f"Vocab vs token ranges mismatch: {offset} != {llama_config.vocab_size}")
-    if "total" in ranges:
-        raise AssertionError('"total" key reserved')
+    """Inclusive ``(first, last)`` id range of every non-empty block of the vocabulary layout, in id order — what
+    ``count_token_types`` counts (reference ``train_utils.py:129-147``; layout ``ssi/extend_llama3_2/__init__.py:100``)."""
+    ranges = {b.name: (b.first, b.last) for b in llama_config.vocab_layout.blocks() if b.count > 0 or b.name != "modality"}
+    assert "total" not in ranges  # reserved by count_token_types for the non-pad count
     return ranges
 
 

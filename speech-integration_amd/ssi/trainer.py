@@ -89,19 +89,18 @@ class TrainingGeometry:
 
     @classmethod
     def from_config(cls, cfg, dataloader, world_size: int) -> "TrainingGeometry":
-        batch_size = cfg.data.train.dataloader.batch_size
-        batches_per_epoch = len(dataloader)
+        """An epoch is the whole number of accumulation windows the loader's batches fill; batches beyond the last full window are
+        dropped at the epoch boundary (warned about once, here); fewer batches than one window is an error."""
         ga = cfg.gradient_accumulation_steps
-        remainder = batches_per_epoch % ga
-        if remainder > 0:
-            LOGGER.warning(f"batches_per_epoch ({batches_per_epoch}) is not divisible by gradient_accumulation_steps ({ga}): "
-                           f"{remainder} remainder batches will be discarded at each epoch boundary.")
-        steps_per_epoch = batches_per_epoch // ga
-        if steps_per_epoch <= 0:
-            raise ValueError(f"batches_per_epoch ({batches_per_epoch}) < gradient_accumulation_steps ({ga})")
-        return cls(batch_size=batch_size, batches_per_epoch=batches_per_epoch, steps_per_epoch=steps_per_epoch,
-                   usable_batches=steps_per_epoch * ga, n_epochs=math.ceil(cfg.max_steps / steps_per_epoch),
-                   gradient_accumulation_steps=ga, world_size=world_size)
+        n_batches = len(dataloader)
+        steps, leftover = divmod(n_batches, ga)
+        if steps == 0:
+            raise ValueError(f"batches_per_epoch ({n_batches}) < gradient_accumulation_steps ({ga}): an epoch would hold no optimizer step")
+        if leftover:
+            LOGGER.warning(f"{leftover} of the {n_batches} batches of an epoch do not fill an accumulation window of {ga} and are skipped "
+                           "at every epoch boundary")
+        return cls(batch_size=cfg.data.train.dataloader.batch_size, batches_per_epoch=n_batches, steps_per_epoch=steps,
+                   usable_batches=steps * ga, n_epochs=-(-cfg.max_steps // steps), gradient_accumulation_steps=ga, world_size=world_size)
 
 
 def resume_position(global_step: int, steps_per_epoch: int, gradient_accumulation_steps: int) -> tuple[int, int]:
@@ -256,20 +255,22 @@ class Trainer:
         if isinstance(self.loss_fn, CEWithChunkedOutputLoss):
             self.model.set_num_output_chunks(self.loss_fn.num_output_chunks)
 
+    def _data_position_hparams(self) -> dict[str, int]:
+        """The values that tie ``global_step`` to a position in the data; written into every training state and compared on resume."""
+        return {"batch_size": self.geometry.batch_size, "gradient_accumulation_steps": self.cfg.gradient_accumulation_steps,
+                "world_size": self.world_size, "steps_per_epoch": self.geometry.steps_per_epoch}
+
     def _finalize_resume(self) -> None:
-        if self._resume_state is None:
+        """Second half of a resume, once the data geometry is known: cumulative counters back in place, data-position check."""
+        state = self._resume_state
+        if state is None:
             return
-        cm = self._resume_state["cumulative_metrics"]
-        self.tokens_train_total = cm["tokens_train_total"]
-        for k, v in cm["token_type_counts"].items():
-            self.token_type_counts_total[k] = v
-        self.wall_clock_offset = cm["wall_clock_seconds"]
-        validate_resume_hparams(
-            ckpt_hparams=self._resume_state["training_hparams"],
-            current_hparams={"batch_size": self.geometry.batch_size,
-                             "gradient_accumulation_steps": self.cfg.gradient_accumulation_steps,
-                             "world_size": self.world_size, "steps_per_epoch": self.geometry.steps_per_epoch},
-            force_resume=self.cfg.get("force_resume", False))
+        totals = state["cumulative_metrics"]
+        self.tokens_train_total = totals["tokens_train_total"]
+        self.token_type_counts_total.update(totals["token_type_counts"])
+        self.wall_clock_offset = totals["wall_clock_seconds"]
+        validate_resume_hparams(ckpt_hparams=state["training_hparams"], current_hparams=self._data_position_hparams(),
+                                force_resume=self.cfg.get("force_resume", False))
 
     def _setup_data_parallel(self) -> None:
         """One process per GPU; gradients exchanged per bucket during backward (``ssi.distributed``)."""
@@ -283,48 +284,50 @@ class Trainer:
 
     # === Training ========================================================================================================
     def train(self) -> None:
+        """Run until ``cfg.max_steps`` optimizer steps have been taken, starting where ``global_step`` says (0, or a resume)."""
         self.optimizer.zero_grad()
-        self.t_train_start = time.perf_counter()
-        self.t_step_start = time.perf_counter()
+        self.t_train_start = self.t_step_start = time.perf_counter()
         self._reset_step_accumulators()
-        epochs_run, batches_to_skip = resume_position(self.global_step, self.geometry.steps_per_epoch, self.cfg.gradient_accumulation_steps)
+        first_epoch, skip = resume_position(self.global_step, self.geometry.steps_per_epoch, self.cfg.gradient_accumulation_steps)
         if self._resume_rng_state is not None:
             from .checkpoint import restore_rng_states
             restore_rng_states(self._resume_rng_state)
-            LOGGER.info("Restored framework RNG states from checkpoint.")
             self._resume_rng_state = None
+            LOGGER.info("python / numpy / torch generator states restored from the training state")
         LOGGER.info(_to_yaml(self.cfg))
         self.wandb_logger.log_config(self.cfg)
-        for epoch in range(epochs_run, self.geometry.n_epochs):
-            self._train_epoch(epoch, batches_to_skip if epoch == epochs_run else 0)
+        for epoch in range(first_epoch, self.geometry.n_epochs):
+            self._train_epoch(epoch, skip if epoch == first_epoch else 0)
             if self.global_step >= self.cfg.max_steps:
-                LOGGER.info("Training completed.")
+                LOGGER.info(f"max_steps={self.cfg.max_steps} reached")
                 return
 
-    def _train_epoch(self, epoch: int, batches_to_skip: int = 0) -> None:
-        if self.sampler_train is not None:
-            self.sampler_train.set_epoch(epoch)
-        if hasattr(self.data_train.dataset, "set_epoch"):
-            self.data_train.dataset.set_epoch(epoch)
-        # batches are collated, pinned and copied to the device two ahead of the step by a background thread (ssi/data/prefetch.py)
+    def _epoch_batches(self, epoch: int, batches_to_skip: int):
+        """``(index, batch)`` pairs of one epoch: the first ``usable_batches`` of the loader (whole accumulation windows only), minus
+        the ones a resumed run has already consumed.  Sampler and dataset are told the epoch (shuffling and the per-sample generators
+        of the CPT data key on it); batches are collated, pinned and copied to the device ahead of the step by a background thread."""
+        for obj in (self.sampler_train, getattr(self.data_train, "dataset", None)):
+            if obj is not None and hasattr(obj, "set_epoch"):
+                obj.set_epoch(epoch)
         source = self.data_train
-        if self.device.type == "cuda" and self.cfg.get("prefetch_batches", 2):
+        depth = int(self.cfg.get("prefetch_batches", 2) or 0)
+        if self.device.type == "cuda" and depth > 0:
             from .data.prefetch import DevicePrefetcher
-            source = DevicePrefetcher(self.data_train, self.device, depth=int(self.cfg.get("prefetch_batches", 2)))
-        if batches_to_skip > 0:
-            LOGGER.info(f"Resuming: skipping {batches_to_skip} batches in epoch {epoch}")
-            data_iter = itertools.islice(enumerate(source), batches_to_skip, self.geometry.usable_batches)
-        else:
-            data_iter = itertools.islice(enumerate(source), self.geometry.usable_batches)
-        ga = self.cfg.gradient_accumulation_steps
-        for i, batch in data_iter:
-            boundary = (i + 1) % ga == 0
-            self._train_step(batch, sync_gradients=boundary)
-            if boundary:
+            source = DevicePrefetcher(self.data_train, self.device, depth=depth)
+        if batches_to_skip:
+            LOGGER.info(f"resume: epoch {epoch} starts at batch {batches_to_skip}")
+        return itertools.islice(enumerate(source), batches_to_skip, self.geometry.usable_batches)
+
+    def _train_epoch(self, epoch: int, batches_to_skip: int = 0) -> None:
+        window = self.cfg.gradient_accumulation_steps
+        for i, batch in self._epoch_batches(epoch, batches_to_skip):
+            closes_window = (i + 1) % window == 0
+            self._train_step(batch, sync_gradients=closes_window)  # gradients are exchanged only by the window's last backward
+            del batch
+            if closes_window:
                 self._optimizer_step(epoch, i)
                 if self.global_step >= self.cfg.max_steps:
                     return
-            del batch
 
     def _train_step(self, batch: dict[str, Tensor], sync_gradients: bool = True) -> None:
         """Single micro-batch forward + backward (``trainer.py:385-395``) with one host sync at the end."""
@@ -405,60 +408,58 @@ class Trainer:
                                     steps_per_epoch=self.geometry.steps_per_epoch, device=self.device)
 
     def _log_metrics(self, epoch: int, iter_idx: int, loss_to_log: float) -> None:
-        LOGGER.info(" | ".join((
-            f"Epoch {epoch + 1:03d}",
-            f"Iteration {iter_idx:0{len(str(self.geometry.batches_per_epoch))}d} / {self.geometry.batches_per_epoch}",
-            f"Global Step {self.global_step}", f"Loss: {loss_to_log:.4f}", f"Tokens (num_tokens_step): {self.num_tokens_step}",
-            *[f"Tokens ({tt}): {c}" for tt, c in self.token_type_counts_total.items()])))
+        """One console line per optimizer step; the metric record (same keys as the reference logs to W&B, ``trainer.py:440-475``) every
+        ``log_interval`` steps from rank 0; the dev loss joins it on steps that evaluate."""
+        width = len(str(self.geometry.batches_per_epoch))
+        per_type = " | ".join(f"Tokens ({kind}): {n}" for kind, n in self.token_type_counts_total.items())
+        LOGGER.info(f"Epoch {epoch + 1:03d} | Iteration {iter_idx:0{width}d} / {self.geometry.batches_per_epoch} | Global Step {self.global_step} | "
+                    f"Loss: {loss_to_log:.4f} | Tokens (num_tokens_step): {self.num_tokens_step}" + (f" | {per_type}" if per_type else ""))
         dev_loss = self._evaluate() if self.global_step % self.cfg.eval_steps == 0 else None
-        if self.global_step % self.cfg.log_interval == 0:
-            dur_step = time.perf_counter() - self.t_step_start
-            log_dict = {
-                "loss": loss_to_log,
-                "lr": get_lr(self.optimizer),
-                "duration_step": dur_step,
-                "tokens_per_second_per_gpu": self.num_tokens_step / dur_step / max(1, self.world_size if self.grad_sync else 1),
-                "tokens_total": self.tokens_train_total,
-                "train_clock_time": (self.wall_clock_offset + (time.perf_counter() - self.t_train_start)) / (60**2),
-                "max_seq_len_step": self.max_seq_len_step,
-                **{f"n_tokens.{tt}": c for tt, c in self.token_type_counts_total.items()},
-            }
-            if self.cfg.clip_grad_norm is not None:
-                log_dict["grad_norm"] = float(self._grad_norm) if self._grad_norm is not None else None
-            if dev_loss is not None:
-                log_dict["dev_loss"] = dev_loss
-            if self.rank == 0:
-                self.wandb_logger.log_dict(log_dict, step=self.global_step)
+        if self.global_step % self.cfg.log_interval:
+            return
+        now = time.perf_counter()
+        step_seconds = now - self.t_step_start
+        ranks = self.world_size if (self.grad_sync is not None and self.world_size) else 1  # num_tokens_step is global under DP
+        record: dict[str, Any] = {
+            "loss": loss_to_log,
+            "lr": get_lr(self.optimizer),
+            "duration_step": step_seconds,
+            "tokens_per_second_per_gpu": self.num_tokens_step / step_seconds / ranks,
+            "tokens_total": self.tokens_train_total,
+            "train_clock_time": (self.wall_clock_offset + now - self.t_train_start) / 3600.0,
+            "max_seq_len_step": self.max_seq_len_step,
+        }
+        record.update({f"n_tokens.{kind}": n for kind, n in self.token_type_counts_total.items()})
+        if self.cfg.clip_grad_norm is not None:
+            record["grad_norm"] = None if self._grad_norm is None else float(self._grad_norm)
+        if dev_loss is not None:
+            record["dev_loss"] = dev_loss
+        if self.rank == 0:
+            self.wandb_logger.log_dict(record, step=self.global_step)
 
     def _maybe_save_checkpoint(self) -> None:
-        if self.global_step != 0 and self.global_step % self.cfg.save_steps == 0:
+        if self.global_step > 0 and self.global_step % self.cfg.save_steps == 0:
             self.save_checkpoint()
-            LOGGER.info(f"Checkpoint saved at step {self.global_step}")
+            LOGGER.info(f"checkpoint written at step {self.global_step}")
 
     def _reset_step_accumulators(self) -> None:
-        self.loss_running = 0.0
-        self.num_tokens_step = 0
-        self.max_seq_len_step = 0
+        self.loss_running, self.num_tokens_step, self.max_seq_len_step = 0.0, 0, 0
         self.t_step_start = time.perf_counter()
 
     # === Checkpointing ===================================================================================================
     def save_checkpoint(self) -> None:
+        """Model weights under ``step_N/`` plus ONE ``training_state.pt`` (schema v1, ``constants.py``) at the checkpoint root —
+        rank 0 only: every rank holds the same weights and optimizer state."""
         if self.rank != 0:
             return
         self.checkpointer.save_model_checkpoint(self.model.state_dict(), self.global_step)
+        elapsed = self.wall_clock_offset + (time.perf_counter() - self.t_train_start)
         self.checkpointer.save_training_state(
             optimizer_state_dict=self.optimizer.state_dict(),
-            lr_scheduler_state_dict=self.lr_scheduler.state_dict() if self.lr_scheduler else None,
-            global_step=self.global_step,
-            seed=SEED,
-            training_hparams={"batch_size": self.geometry.batch_size,
-                              "gradient_accumulation_steps": self.cfg.gradient_accumulation_steps,
-                              "world_size": self.world_size, "steps_per_epoch": self.geometry.steps_per_epoch},
-            consumed_samples=self.consumed_samples,
-            cumulative_metrics={"tokens_train_total": self.tokens_train_total,
-                                "token_type_counts": dict(self.token_type_counts_total),
-                                "wall_clock_seconds": self.wall_clock_offset + (time.perf_counter() - self.t_train_start)},
-        )
+            lr_scheduler_state_dict=None if self.lr_scheduler is None else self.lr_scheduler.state_dict(),
+            global_step=self.global_step, seed=SEED, training_hparams=self._data_position_hparams(), consumed_samples=self.consumed_samples,
+            cumulative_metrics={"tokens_train_total": self.tokens_train_total, "token_type_counts": dict(self.token_type_counts_total),
+                                "wall_clock_seconds": elapsed})
 
     # === Cleanup =========================================================================================================
     def cleanup(self) -> None:
