@@ -510,13 +510,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 // PREV: 0 = C is overwritten, 1 = C += result (accumulate), 2 = C = R + result (residual)
 // SPLITK: a unit of work is (output tile, K-slice); the fp32 partial tile goes to the workspace in the accumulator's own layout
 //      (unit, wave, 16x16 tile, lane: every store is one contiguous KiB) and nt4_splitk_reduce_kernel finishes the tile
-template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK = false>
-__global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, int tiles_n, int64_t K, const bf16_t* __restrict__ A,
-                                                                  int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
-                                                                  bf16_t* __restrict__ C, int64_t ldc, const bf16_t* __restrict__ R,
-                                                                  float alpha, const float* __restrict__ alpha_dev, EpiArgs ea, int slot,  // slot < 0: static tile order
-                                                                  int splits, float* __restrict__ slabs) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// DMA (k-contiguous operands only): the operand stream goes HBM -> LDS by LDS-DMA (buffer_load ... lds, no staging registers, no
+//      ds_write) two K-steps ahead, and the registers hold a whole K-step of fragments instead (see the DMA main loop below)
+template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK, bool DMA>
+__device__ __forceinline__ void nt4_body(char* smem, int tiles_m, int tiles_n, int64_t K, const bf16_t* __restrict__ A,
+                                         int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                         bf16_t* __restrict__ C, int64_t ldc, const bf16_t* __restrict__ R,
+                                         float alpha, const float* __restrict__ alpha_dev, EpiArgs ea, int slot,  // slot < 0: static tile order
+                                         int splits, float* __restrict__ slabs) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -712,6 +713,127 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
         blk(S3, 1, S2, 0, F_{}, [&](int q) { if (q < 4) rdB1(S1[q], nb, 0, 0, q); });
     };
     u32x4 ra0[8], rb0[8], ra1[8], rb1[8];
+    // ---- DMA main loop (NT form) ---------------------------------------------------------------------------------------------
+    // LDS: the same two [A | B] buffers and the same swizzled row image as the register-staged path, but filled by LDS-DMA: a
+    // piece = one wave-instruction = 8 rows x 128 B, lane-linear in LDS, the 16-byte-chunk swizzle applied to the per-lane SOURCE
+    // address.  Per K-step and wave: 128 MFMAs, 32 ds_read_b128, 16 DMA issues, two barriers; nothing else touches a VGPR.
+    //   registers : F0 = the 8 A + 8 B fragments of the k-half 0 of this K-step, F1 = those of k-half 1 (128 VGPRs)
+    //   phase A   : 64 MFMAs on F0.  Under them F1 is read from this K-step's LDS buffer; once every wave has done so (barrier) the
+    //               buffer is free and the DMA of K-step +2 starts into it
+    //   phase B   : 64 MFMAs on F1.  The DMA of K-step +1 (issued one K-step ago) is waited for (counted vmcnt: this K-step's 16
+    //               pieces stay in flight) + barrier, then F0 of the next K-step is read from the other buffer
+    bf16x8 F0A[8], F0B[8], F1A[8], F1B[8];
+    const int dofA = (int)(((tid >> 3) * lda + (((tid & 7) ^ ((tid >> 4) & 7)) * 8)) * 2);
+    const int dofB = (int)(((tid >> 3) * ldb + (((tid & 7) ^ ((tid >> 4) & 7)) * 8)) * 2);
+    // One piece = buffer_load_dwordx4 ... lds: LDS destination = M0 + lane * 16.  M0 is written one MFMA AHEAD of the load (dma_m0 then
+    // dma_go): written right in front of it, as the builtin form does, every piece stalls the wave's issue for ~50 cycles (measured:
+    // SQ_WAIT_INST_ANY +25 %, the loop 18 % longer); with an MFMA in between the wait disappears under the matrix pipe.
+    typedef __attribute__((address_space(3))) char lds_c;
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)smem + (unsigned)wave * 1024u);  // one cast, then integers
+    auto rsrc_words = [&](const bf16_t* base) {  // raw buffer resource: base, stride 0, 2 GiB window, 32-bit data format
+        const uint64_t a = (uint64_t)(uintptr_t)base;
+        u32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+        r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+        r[2] = 0x7fffffffu;
+        r[3] = BUF_RSRC_DW3;
+        return r;
+    };
+    auto dma_m0 = [&](int buf, int d) {  // piece d: 0..7 = A rows d*32 .. +31, 8..15 = B
+        const unsigned dst = lds_wave + (unsigned)((d < 8 ? buf * TILE_BYTES : 2 * TILE_BYTES + buf * TILE_BYTES) + (d & 7) * 4096);  // tileA / tileB
+        asm volatile("s_mov_b32 m0, %0" ::"s"(dst) : "memory");
+    };
+    u32x4 rsA, rsB;  // buffer resources of the K-step being fetched (set once per K-step by dma_src)
+    auto dma_src = [&]() { rsA = rsrc_words(baseA + lkt * kstepA); rsB = rsrc_words(baseB + lkt * kstepB); };
+    // k-contiguous operand: 8 rows x 128 B per piece, swizzled source chunk (dofA / dofB); k-strided operand: 2 k-rows x 512 B per piece with
+    // the register path's own source offsets (its LDS image is lane-linear already)
+    auto dma_go = [&](int d) {
+        if (d < 8) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(A_COL ? ((d & 1) ? offA1 : offA0) : dofA), "s"(rsA), "s"(pieceA(d)) : "memory");
+        else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(B_COL ? ((d & 1) ? offB1 : offB0) : dofB), "s"(rsB), "s"(pieceB(d - 8)) : "memory");
+    };
+    auto dma = [&](int buf, int d) {  // prologue form: no MFMA to hide behind
+        dma_m0(buf, d);
+        asm volatile("s_nop 1" ::: "memory");
+        dma_go(d);
+    };
+    auto fragA = [&](const char* t, int i, int kh) {
+        if constexpr (A_COL) return rd_tr(t, trA, i, kh);
+        else return read_frag<false>(t, wm * NT4_WM + i * 16, kh, lane);
+    };
+    auto fragB = [&](const char* t, int j, int kh) {
+        if constexpr (B_COL) return rd_tr(t, trB, j, kh);
+        else return read_frag<false>(t, wn * NT4_WN + j * 16, kh, lane);
+    };
+    // 64 MFMAs: every accumulator tile once, A fragment outer; extra(m) is issued right after MFMA m and pinned there
+    auto phase = [&](const bf16x8 (&fa)[8], const bf16x8 (&fb)[8], auto zero_c, auto extra) {
+#pragma unroll
+        for (int m = 0; m < 64; ++m) {
+            const int i = m >> 3, j = m & 7;
+            if (decltype(zero_c)::value)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[j][i]) : "v"(fb[j]), "v"(fa[i]));
+            else
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j][i]) : "v"(fb[j]), "v"(fa[i]));
+            extra(m);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto dma_body = [&](auto cur_c, auto first) {
+        static_assert(!(DMA && SPLITK), "the LDS-DMA loop has no split-K instantiation (it spills)");
+        constexpr int cur = decltype(cur_c)::value;
+        if (A_COL) asm volatile("" : "+v"(trA));  // keep the per-read XOR of the transposed-read addresses from being hoisted into 16 registers
+        if (B_COL) asm volatile("" : "+v"(trB));
+        const char* la = tileA(cur);
+        const char* lb = tileB(cur);
+        const char* na = tileA(cur ^ 1);
+        const char* nb = tileB(cur ^ 1);
+        // DMA pieces are spread over the rest of the K-step (4 waves x 1 KiB every ~5 MFMAs keeps the CU's load path about half busy; bunched
+        // right behind the barrier the pieces queue up and every issue stalls the wave): pieces 0..3 in phase A, 4..15 in phase B
+        phase(F0A, F0B, first, [&](int m) {
+            if (m < 32 && !(m & 1)) {
+                const int r = m >> 1;
+                if (r < 8) F1B[r] = fragB(lb, r, 1); else F1A[r - 8] = fragA(la, r - 8, 1);
+            }
+            if (m == 40) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave holds its F1: this buffer may be overwritten
+                dma_src();
+            }
+            if (m >= 43 && (m - 43) % 6 == 0) dma_m0(cur, (m - 43) / 6);   // 43, 49, 55, 61
+            if (m >= 44 && (m - 44) % 6 == 0) dma_go((m - 44) / 6);        // 44, 50, 56, 62
+        });
+        phase(F1A, F1B, F_{}, [&](int m) {
+            if (m >= 2 && m < 60 && (m - 2) % 5 == 0) dma_m0(cur, 4 + (m - 2) / 5);  // 2, 7, ..., 57
+            if (m >= 3 && m < 60 && (m - 3) % 5 == 0) dma_go(4 + (m - 3) / 5);       // 3, 8, ..., 58
+            if (m == 11) {
+                advance();
+                // K-step +1 (16 pieces issued during the last K-step) has landed for this wave — the 6 pieces of this K-step issued so far
+                // may still be in flight — and, with the barrier, for every wave
+                asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            }
+            // next K-step's F0 from the other buffer: 16 reads on the even slots 12..50 that carry no DMA issue (18, 28, 38, 48 do)
+            if (m >= 12 && m <= 50 && !(m & 1) && m % 10 != 8) {
+                const int r = (m - 12) / 2 - (m - 8) / 10;
+                if (r < 8) F0B[r] = fragB(nb, r, 0); else F0A[r - 8] = fragA(na, r - 8, 0);
+            }
+        });
+    };
+    if constexpr (DMA) {
+        set_load_tile(cur >= 0 ? cur : 0);
+        if (nk_total == 0) return;
+        dma_src();
+#pragma unroll
+        for (int d = 0; d < 16; ++d) dma(0, d);
+        advance();
+        dma_src();
+#pragma unroll
+        for (int d = 0; d < 16; ++d) dma(1, d);
+        advance();
+        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");  // K-step 0 is in LDS
+#pragma unroll
+        for (int r = 0; r < 8; ++r) F0B[r] = fragB(tileB(0), r, 0);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) F0A[r] = fragA(tileA(0), r, 0);
+        if (cur >= 0 && !dynamic) nxt = receive_tile();
+    } else {
     auto fetch_step = [&](u32x4 (&xa)[8], u32x4 (&xb)[8]) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) gloadA(xa[p], p);
@@ -733,6 +855,7 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     for (int q = 0; q < 4; ++q) { rdA1(S0[q], tileA(0), 0, 0, q); rdB1(S1[q], tileB(0), 0, 0, q); }
     if (cur >= 0 && !dynamic) nxt = receive_tile();
 
+    }
     const float al = alpha * (alpha_dev ? *alpha_dev : 1.f);
     const int g = lane >> 4;
     while (cur >= 0) {
@@ -744,11 +867,20 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
         // the tile after next is requested now and read after the epilogue: the answer is the oldest vector-memory operation in
         // flight, so the counted waits of the K-steps below retire it (asking later would mean waiting for the epilogue's stores)
         if (nxt >= 0) request_tile();
-        body(B0_{}, ra1, rb1, std::true_type{});
-        body(B1_{}, ra0, rb0, F_{});
-        for (int kt = 2; kt < nk; kt += 2) {
-            body(B0_{}, ra1, rb1, F_{});
+        if constexpr (DMA) {
+            dma_body(B0_{}, std::true_type{});
+            dma_body(B1_{}, F_{});
+            for (int kt = 2; kt < nk; kt += 2) {
+                dma_body(B0_{}, F_{});
+                dma_body(B1_{}, F_{});
+            }
+        } else {
+            body(B0_{}, ra1, rb1, std::true_type{});
             body(B1_{}, ra0, rb0, F_{});
+            for (int kt = 2; kt < nk; kt += 2) {
+                body(B0_{}, ra1, rb1, F_{});
+                body(B1_{}, ra0, rb0, F_{});
+            }
         }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the asm MFMAs are opaque to the hazard recogniser: let the last results land
         // ---- epilogue: acc[j][i] holds C[m = wm*128 + i*16 + (lane&15)][n = wn*128 + j*16 + (lane>>4)*4 + r] -------------
@@ -980,9 +1112,11 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
         cur = nxt;
         if (cur >= 0) nxt = receive_tile();
         // the first fragments of the next tile (its K-step 0 sits in LDS buffer 0) are read again here rather than kept live
-        // across the epilogue
+        // across the epilogue (the DMA path keeps its F0 live: it has no staging registers to make room for)
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { rdA1(S0[q], tileA(0), 0, 0, q); rdB1(S1[q], tileB(0), 0, 0, q); }
+            for (int q = 0; q < 4; ++q) { rdA1(S0[q], tileA(0), 0, 0, q); rdB1(S1[q], tileB(0), 0, 0, q); }
+        }
     }
     // the last workgroup to get here clears the scheduler slot for the launch that uses it next
     if (dynamic && tid == 0 && atomicAdd(&sched[8], 1) == G - 1) {  // plain stores: nobody reads the slot before this kernel has ended
@@ -990,6 +1124,27 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
 #pragma unroll
         for (int i = 0; i < 9; ++i) vs[i] = 0;
     }
+}
+
+template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK = false>
+__global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, int tiles_n, int64_t K, const bf16_t* __restrict__ A,
+                                                                  int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                                  bf16_t* __restrict__ C, int64_t ldc, const bf16_t* __restrict__ R,
+                                                                  float alpha, const float* __restrict__ alpha_dev, EpiArgs ea, int slot,
+                                                                  int splits, float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    nt4_body<A_COL, B_COL, EPI, PREV, SPLITK, false>(smem, tiles_m, tiles_n, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, ea, slot, splits, slabs);
+}
+
+// the LDS-DMA main loop (same tile walk, scheduler and epilogues)
+template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK = false>
+__global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4dma_kernel(int tiles_m, int tiles_n, int64_t K, const bf16_t* __restrict__ A,
+                                                                     int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                                     bf16_t* __restrict__ C, int64_t ldc, const bf16_t* __restrict__ R,
+                                                                     float alpha, const float* __restrict__ alpha_dev, EpiArgs ea, int slot,
+                                                                     int splits, float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    nt4_body<A_COL, B_COL, EPI, PREV, SPLITK, true>(smem, tiles_m, tiles_n, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, ea, slot, splits, slabs);
 }
 
 // Finishes split-K tiles: one wave per (output tile, wave of the GEMM workgroup, m-tile i, 64-column duo).  Sums the K-slices'
@@ -1053,11 +1208,14 @@ __global__ __launch_bounds__(256) void nt4_splitk_reduce_kernel(const float* __r
     finish(hi, base + 8 * ldc);
 }
 
-template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK = false>
+template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK = false, bool DMA = false>
 int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                const void* R, float alpha, const float* alpha_dev, hipStream_t st, EpiArgs ea = EpiArgs{nullptr, 0, nullptr, 0, 0},
                int splits = 1, float* slabs = nullptr) {
-    auto kern = gemm_nt4_kernel<A_COL, B_COL, EPI, PREV, SPLITK>;
+    void (*kern)(int, int, int64_t, const bf16_t*, int64_t, const bf16_t*, int64_t, bf16_t*, int64_t, const bf16_t*, float, const float*, EpiArgs, int, int,
+                 float*);
+    if constexpr (DMA) kern = gemm_nt4dma_kernel<A_COL, B_COL, EPI, PREV, SPLITK>;
+    else kern = gemm_nt4_kernel<A_COL, B_COL, EPI, PREV, SPLITK>;
     // one-time set-up per instantiation as C++11 thread-safe statics: the forward thread and autograd's backward thread may both be the
     // first to launch a given form
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NT4_LDS_BYTES);
@@ -1076,6 +1234,19 @@ int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, 
     return SSI_OK;
 }
 
+// Main loop of the persistent kernel per operand form: 1 = LDS-DMA (default: +7..15 % on every form of the step, profiles/r02_*), 0 = the
+// register-staged loop (kept for A/B builds: -DSSI_NT_DMA=0 -DSSI_NN_DMA=0 -DSSI_TN_DMA=0)
+#ifndef SSI_NT_DMA
+#define SSI_NT_DMA 1
+#endif
+constexpr bool NT_DMA = SSI_NT_DMA != 0;
+#ifndef SSI_NN_DMA
+#define SSI_NN_DMA 1
+#endif
+#ifndef SSI_TN_DMA
+#define SSI_TN_DMA 1
+#endif
+constexpr bool NN_DMA = SSI_NN_DMA != 0, TN_DMA = SSI_TN_DMA != 0;
 bool nt4_ok(int64_t K) { return K % (2 * BK) == 0 && K >= 4 * BK && ssi_get_impl() != SSI_IMPL_MFMA_WG8; }
 // buffer-load offsets are 32-bit: a tile's rows (k-contiguous) or one K-step's k-rows (k-strided) must stay within 2 GiB
 bool nt4_ld_ok(int64_t lda, int64_t ldb) { return 256 * lda * 2 < (1LL << 31) && 256 * ldb * 2 < (1LL << 31); }
@@ -1104,23 +1275,23 @@ int ssi_gemm_mfma_bf16(int layout, int64_t M, int64_t N, int64_t K, const void* 
     switch (layout) {
         case SSI_GEMM_NT:
             if (nt4_ok(K) && nt4_ld_ok(lda, ldb) && !(accumulate && R)) {
-                if (accumulate) return launch_nt4<false, false, EPI_PLAIN, 1>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
-                if (R) return launch_nt4<false, false, EPI_PLAIN, 2>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
-                return launch_nt4<false, false, EPI_PLAIN, 0>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (accumulate) return launch_nt4<false, false, EPI_PLAIN, 1, false, NT_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (R) return launch_nt4<false, false, EPI_PLAIN, 2, false, NT_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                return launch_nt4<false, false, EPI_PLAIN, 0, false, NT_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
             }
             GO(false, false);
         case SSI_GEMM_NN:
             if (nt4_ok(K) && nt4_ld_ok(lda, ldb) && !(accumulate && R)) {
-                if (accumulate) return launch_nt4<false, true, EPI_PLAIN, 1>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
-                if (R) return launch_nt4<false, true, EPI_PLAIN, 2>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
-                return launch_nt4<false, true, EPI_PLAIN, 0>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (accumulate) return launch_nt4<false, true, EPI_PLAIN, 1, false, NN_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (R) return launch_nt4<false, true, EPI_PLAIN, 2, false, NN_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                return launch_nt4<false, true, EPI_PLAIN, 0, false, NN_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
             }
             GO(false, true);
         case SSI_GEMM_TN:
             if (nt4_ok(K) && nt4_ld_ok(lda, ldb) && !(accumulate && R)) {
-                if (accumulate) return launch_nt4<true, true, EPI_PLAIN, 1>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
-                if (R) return launch_nt4<true, true, EPI_PLAIN, 2>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
-                return launch_nt4<true, true, EPI_PLAIN, 0>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (accumulate) return launch_nt4<true, true, EPI_PLAIN, 1, false, TN_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                if (R) return launch_nt4<true, true, EPI_PLAIN, 2, false, TN_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
+                return launch_nt4<true, true, EPI_PLAIN, 0, false, TN_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
             }
             GO(true, true);
     }
@@ -1135,7 +1306,8 @@ int ssi_gemm_mfma_bf16_splitk(int layout, int64_t M, int64_t N, int64_t K, const
     auto st = (hipStream_t)stream;
     // weight-gradient form on the persistent kernel: units = tile x K-slice, every slice at least 6 K-steps, no residual
     if (layout == SSI_GEMM_TN && nt4_ok(K) && nt4_ld_ok(lda, ldb) && !R && K / BK / splits >= 6 && ldc % 8 == 0) {
-        if (int rc = launch_nt4<true, true, EPI_PLAIN, 0, true>(tm, tn, K, A, lda, B, ldb, C, ldc, nullptr, 1.f, nullptr, st,
+        // (register-staged loop: the LDS-DMA loop's split-K instantiation spills under hipcc 7.2 — 1100 scratch accesses — and is not used)
+        if (int rc = launch_nt4<true, true, EPI_PLAIN, 0, true, false>(tm, tn, K, A, lda, B, ldb, C, ldc, nullptr, 1.f, nullptr, st,
                                                                  EpiArgs{nullptr, 0, nullptr, 0, 0}, splits, slabs)) return rc;
         hipLaunchKernelGGL(nt4_splitk_reduce_kernel, dim3((unsigned)ssi_cdiv((int64_t)tm * tn * 64, 4)), dim3(256), 0, st, slabs, splits, tm, tn,
                            (bf16_t*)C, ldc, alpha, alpha_dev, accumulate);
@@ -1159,7 +1331,7 @@ bool ssi_gemm_rope_mfma(int64_t M, int64_t N, int64_t K, const void* A, int64_t 
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return false;
     EpiArgs ea{nullptr, 0, nullptr, 0, 0};
     ea.rope = rope; ea.pos = positions; ea.seq = seq; ea.rot_cols = rot_cols;
-    *rc = launch_nt4<false, false, EPI_ROPE, 0>((int)(M / BM), (int)(N / BN), K, A, lda, B, ldb, C, ldc, nullptr, 1.f, nullptr,
+    *rc = launch_nt4<false, false, EPI_ROPE, 0, false, NT_DMA>((int)(M / BM), (int)(N / BN), K, A, lda, B, ldb, C, ldc, nullptr, 1.f, nullptr,
                                                 (hipStream_t)stream, ea);
     return true;
 }
@@ -1177,7 +1349,7 @@ int ssi_gemm_swiglu_fwd_mfma(int64_t M, int64_t inter, int64_t K, const void* X,
                              void* GU, int64_t ldgu, void* ACT, int64_t ldact, void* stream) {
     EpiArgs ea{(bf16_t*)ACT, ldact, nullptr, 0, inter};
     if (nt4_ok(K))
-        return launch_nt4<false, false, EPI_SWIGLU_FWD, 0>((int)(M / BM), (int)(2 * inter / BN), K, X, ldx, W13, ldw, GU, ldgu, nullptr, 1.f, nullptr,
+        return launch_nt4<false, false, EPI_SWIGLU_FWD, 0, false, NT_DMA>((int)(M / BM), (int)(2 * inter / BN), K, X, ldx, W13, ldw, GU, ldgu, nullptr, 1.f, nullptr,
                                              (hipStream_t)stream, ea);
     // output tiles: 256 rows x (128 gate + 128 up) columns -> tiles_n = 2I / 256
     return launch<false, false, false, EPI_SWIGLU_FWD>((int)(M / BM), (int)(2 * inter / BN), K, X, ldx, W13, ldw, GU, ldgu, nullptr, 1.f,
@@ -1191,11 +1363,11 @@ int ssi_gemm_swiglu_bwd_mfma(int layout, int64_t M, int64_t inter, int64_t K, co
     const int tm = (int)(M / BM), tn = (int)(inter / BN);
     if (layout == SSI_GEMM_NN) {
         if (nt4_ok(K) && nt4_ld_ok(lddy, ldw))
-            return launch_nt4<false, true, EPI_SWIGLU_BWD, 0>(tm, tn, K, DY, lddy, W2, ldw, DGU, lddgu, nullptr, 1.f, nullptr, (hipStream_t)stream, ea);
+            return launch_nt4<false, true, EPI_SWIGLU_BWD, 0, false, NN_DMA>(tm, tn, K, DY, lddy, W2, ldw, DGU, lddgu, nullptr, 1.f, nullptr, (hipStream_t)stream, ea);
         return SSI_ERR_UNSUPPORTED;
     }
     if (nt4_ok(K) && nt4_ld_ok(lddy, ldw))
-        return launch_nt4<false, false, EPI_SWIGLU_BWD, 0>(tm, tn, K, DY, lddy, W2, ldw, DGU, lddgu, nullptr, 1.f, nullptr, (hipStream_t)stream, ea);
+        return launch_nt4<false, false, EPI_SWIGLU_BWD, 0, false, NT_DMA>(tm, tn, K, DY, lddy, W2, ldw, DGU, lddgu, nullptr, 1.f, nullptr, (hipStream_t)stream, ea);
     return launch<false, false, false, EPI_SWIGLU_BWD>(tm, tn, K, DY, lddy, W2, ldw, DGU, lddgu, nullptr, 1.f, nullptr, 0, (hipStream_t)stream, 1,
                                                        nullptr, ea);
 }
