@@ -376,10 +376,10 @@ def main() -> int:
             out["gflop_per_token"] = f_tok / 1e9
         if timer.records:
             _, _, per = timer.summary()
-            # one kernel symbol per (operand layout, epilogue) class: gemm_nt4_kernel<A_COL, B_COL, EPI_PLAIN, PREV, SPLITK=false>; the roofline
+            # one kernel symbol per (operand layout, epilogue) class: gemm_nt4dma_kernel<A_COL, B_COL, EPI_PLAIN, PREV, SPLITK=false> (the LDS-DMA loop); the roofline
             # object is the class with the largest share of the step
             lay = {0: "false,false", 1: "false,true", 2: "true,true"}
-            sym = {(l, pv): f"gemm_nt4_kernel<{lay[l]},0,{pv},false>" for l in lay for pv in (0, 1, 2)}
+            sym = {(l, pv): f"gemm_nt4dma_kernel<{lay[l]},0,{pv},false>" for l in lay for pv in (0, 1, 2)}
             dom = max(per, key=lambda k: per[k][1])
             n, ms, fl = per[dom]
             out["roofline"] = {

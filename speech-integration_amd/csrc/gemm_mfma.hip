@@ -490,6 +490,15 @@ int launch(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, cons
 #ifndef NT4_ST_AUX_BIG  // outputs far larger than the 256 MiB Infinity Cache (gate/up/act of the fused SwiGLU forward, 0.8 GB)
 #define NT4_ST_AUX_BIG 2
 #endif
+// schedule of the LDS-DMA loop (slots = MFMA indices inside a 64-MFMA phase): F1 reads every NT4_RS MFMAs from slot 0, barrier at NT4_BAR,
+// NT4_NA pieces in phase A at NT4_A0 + i * NT4_SA, the other pieces in phase B at 3 + 5 i
+#ifndef NT4_RS
+#define NT4_RS 2
+#define NT4_BAR 40
+#define NT4_A0 44
+#define NT4_SA 6
+#define NT4_NA 4
+#endif
 constexpr int NT4_THREADS = 256;
 constexpr int NT4_LDS_BYTES = PIPE_BYTES + 16;  // operand pipeline + the scheduler's broadcast word
 std::atomic<int> g_nt4_dynamic{0};
@@ -787,27 +796,32 @@ __device__ __forceinline__ void nt4_body(char* smem, int tiles_m, int tiles_n, i
         const char* na = tileA(cur ^ 1);
         const char* nb = tileB(cur ^ 1);
         // DMA pieces are spread over the rest of the K-step (4 waves x 1 KiB every ~5 MFMAs keeps the CU's load path about half busy; bunched
-        // right behind the barrier the pieces queue up and every issue stalls the wave): pieces 0..3 in phase A, 4..15 in phase B
+        // right behind the barrier the pieces queue up and every issue stalls the wave): pieces 0..NA-1 in phase A, the rest in phase B
+        constexpr int RS = NT4_RS, BAR = NT4_BAR, A0 = NT4_A0, SA = NT4_SA, NA = NT4_NA;
+        static_assert(15 * RS + 4 <= BAR && BAR + 2 <= A0 - 1 && A0 + (NA - 1) * SA <= 63 && 3 + 5 * (15 - NA) <= 58, "DMA schedule");
         phase(F0A, F0B, first, [&](int m) {
-            if (m < 32 && !(m & 1)) {
-                const int r = m >> 1;
+            if (m < 16 * RS && m % RS == 0) {
+                const int r = m / RS;
                 if (r < 8) F1B[r] = fragB(lb, r, 1); else F1A[r - 8] = fragA(la, r - 8, 1);
             }
-            if (m == 40) {
+            if (m == BAR) {
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave holds its F1: this buffer may be overwritten
                 dma_src();
             }
-            if (m >= 43 && (m - 43) % 6 == 0) dma_m0(cur, (m - 43) / 6);   // 43, 49, 55, 61
-            if (m >= 44 && (m - 44) % 6 == 0) dma_go((m - 44) / 6);        // 44, 50, 56, 62
+            if (m >= A0 - 1 && m < A0 - 1 + NA * SA && (m - (A0 - 1)) % SA == 0) dma_m0(cur, (m - (A0 - 1)) / SA);
+            if (m >= A0 && m < A0 + NA * SA && (m - A0) % SA == 0) dma_go((m - A0) / SA);
         });
         phase(F1A, F1B, F_{}, [&](int m) {
-            if (m >= 2 && m < 60 && (m - 2) % 5 == 0) dma_m0(cur, 4 + (m - 2) / 5);  // 2, 7, ..., 57
-            if (m >= 3 && m < 60 && (m - 3) % 5 == 0) dma_go(4 + (m - 3) / 5);       // 3, 8, ..., 58
+            if (m >= 2 && m < 2 + 5 * (16 - NA) && (m - 2) % 5 == 0) dma_m0(cur, NA + (m - 2) / 5);  // 2, 7, ...
+            if (m >= 3 && m < 3 + 5 * (16 - NA) && (m - 3) % 5 == 0) dma_go(NA + (m - 3) / 5);       // 3, 8, ...
             if (m == 11) {
                 advance();
-                // K-step +1 (16 pieces issued during the last K-step) has landed for this wave — the 6 pieces of this K-step issued so far
-                // may still be in flight — and, with the barrier, for every wave
-                asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+                // K-step +1 (16 pieces issued during the last K-step) has landed for this wave — the NA + 2 pieces of this K-step issued so
+                // far may still be in flight — and, with the barrier, for every wave
+                if constexpr (NA == 4) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+                else if constexpr (NA == 6) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                else if constexpr (NA == 7) asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             }
             // next K-step's F0 from the other buffer: 16 reads on the even slots 12..50 that carry no DMA issue (18, 28, 38, 48 do)
             if (m >= 12 && m <= 50 && !(m & 1) && m % 10 != 8) {
