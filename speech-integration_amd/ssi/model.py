@@ -148,9 +148,9 @@ class HipLlamaDecoder(nn.Module):
         self._flat_numel = off
         self._flat = torch.zeros(off, dtype=dtype, device=device)
         self._flat_grad = torch.zeros(off, dtype=dtype, device=device)
-        # [in, out] copies of the 2-D weights (same offsets, transposed shapes): data-gradient GEMMs dX = dY W then run in
-        # the k-contiguous operand form (the transposed-read form is ~20 % slower); refreshed lazily
-        self._flat_t: Optional[Tensor] = None
+        # [in, out] copies of the weights named by `dgrad_transposed`: their data-gradient GEMMs dX = dY W then run in the
+        # k-contiguous operand form; refreshed lazily after the weights change (one transpose launch per weight per optimizer step)
+        self._wt: dict[str, Tensor] = {}
         self._wt_key: Optional[tuple] = None
         self._hip_epoch = 0  # bumped by kernels that modify the weights in place (fused AdamW)
         self._grad_views: dict[str, Tensor] = {}
@@ -250,28 +250,41 @@ class HipLlamaDecoder(nn.Module):
                     p.copy_(src.to(device=self.device, dtype=self.dtype))
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
-    # Data gradients dX = dY W run on the untransposed weights (NN form of the persistent GEMM, as fast as the k-contiguous
-    # form); SSI_DGRAD_NT=1 restores the older scheme of [in, out] weight copies refreshed after every optimizer step.
-    transposed_weight_copies = os.environ.get("SSI_DGRAD_NT", "0") == "1"
+    # Data gradients dX = dY W run on the untransposed weights (NN form of the persistent GEMM).  `dgrad_transposed` names weights whose
+    # data gradient should instead run in the k-contiguous (NT) form on an [in, out] copy refreshed after every optimizer step: none
+    # by default.  Measured inside the step (profiles/r02_b, bench.py per-class GEMM timing): W13's data gradient takes 0.701 ms as NN
+    # and 0.696 ms as NT, while the 16 transposes cost 0.75 ms — alone on the GPU the NN form looks 17 % slower (913 vs 779 us), but in the
+    # step its A operand has just been written and is served from the Infinity Cache.  SSI_DGRAD_NT=1: copies of every 2-D weight.
+    dgrad_transposed: tuple = {"1": ("emb", "wqkv", "wo", "w13", "w2"), "w13": ("w13",)}.get(os.environ.get("SSI_DGRAD_NT", ""), ())
+
+    @property
+    def transposed_weight_copies(self) -> bool:
+        return len(self.dgrad_transposed) > 0
+
+    @transposed_weight_copies.setter
+    def transposed_weight_copies(self, on: bool) -> None:  # tests: all weights or none
+        self.dgrad_transposed = ("emb", "wqkv", "wo", "w13", "w2") if on else ()
+        self._wt, self._wt_key = {}, None
+
+    def _has_t(self, name: str) -> bool:
+        return name.rsplit(".", 1)[-1] in self.dgrad_transposed and self._mfma_shapes()
 
     def _view_t(self, name: str) -> Tensor:
-        o, shape = self._slices[name]
-        return self._flat_t[o:o + shape[0] * shape[1]].view(shape[1], shape[0])
+        return self._wt[name]
 
-    def _ensure_transposed(self) -> bool:
-        """Refresh the transposed weight copies if any weight changed since the last refresh.  Returns whether the
-        transposed copies are in use (bf16 MFMA shapes only)."""
-        if not self.transposed_weight_copies or not self._mfma_shapes():
-            return False
+    def _ensure_transposed(self) -> None:
+        """Refresh the [in, out] copies if any weight changed since the last refresh."""
+        if not self.dgrad_transposed or not self._mfma_shapes():
+            return
         key = (self._flat._version, self._hip_epoch)
-        if self._flat_t is None:
-            self._flat_t = torch.empty_like(self._flat)
-        if key != self._wt_key:
-            for name, (o, shape) in self._slices.items():
-                if len(shape) == 2:
-                    ops.transpose(self._view(name), self._view_t(name))
-            self._wt_key = key
-        return True
+        if key == self._wt_key:
+            return
+        for name, (o, shape) in self._slices.items():
+            if len(shape) == 2 and self._has_t(name):
+                if name not in self._wt:
+                    self._wt[name] = torch.empty((shape[1], shape[0]), dtype=self.dtype, device=self.device)
+                ops.transpose(self._view(name), self._wt[name])
+        self._wt_key = key
 
     def attach_grads(self) -> None:
         """Point every ``p.grad`` at its slice of the flat gradient buffer (idempotent)."""
@@ -402,11 +415,11 @@ class HipLlamaDecoder(nn.Module):
                 ops.gemm(GEMM_TN, dy, x, g, accumulate=True)
 
         sync = self.grad_sync if (self.grad_sync is not None and self.sync_this_backward) else None
-        use_t = self._ensure_transposed()
+        self._ensure_transposed()
 
         def dgrad(dy: Tensor, name: str, dx: Tensor) -> None:
-            """dx = dy @ W  (W = [out, in]); NT form on the [in, out] copy when available."""
-            if use_t:
+            """dx = dy @ W  (W = [out, in]); NT form on the [in, out] copy where one is kept."""
+            if self._has_t(name):
                 ops.gemm(GEMM_NT, dy, self._view_t(name), dx)
             else:
                 ops.gemm(GEMM_NN, dy, self._view(name), dx)
@@ -424,7 +437,7 @@ class HipLlamaDecoder(nn.Module):
             # MLP: h_out = hmid + act @ w2^T
             wgrad(dh, act, f"L{l}.w2")
             dgu = A.get("dgu", (T, 2 * I), dt)
-            if use_t:  # d act = dh W2 never reaches memory: the SwiGLU backward rides in the GEMM epilogue
+            if self._has_t(f"L{l}.w2"):  # d act = dh W2 never reaches memory: the SwiGLU backward rides in the GEMM epilogue
                 ops.gemm_swiglu_bwd(GEMM_NT, dh, self._view_t(f"L{l}.w2"), gu, dgu, None)
             else:
                 ops.gemm_swiglu_bwd(GEMM_NN, dh, self._view(f"L{l}.w2"), gu, dgu, A.get("dact", (T, I), dt))
@@ -473,7 +486,8 @@ class HipLlamaDecoder(nn.Module):
         T, D = hn.shape
         self._grads_dirty = True
         d_hn = self._arena.get("d_hn", (T, D), self.dtype)
-        if self._ensure_transposed():
+        self._ensure_transposed()
+        if self._has_t("emb"):
             ops.gemm(GEMM_NT, dlogits, self._view_t("emb"), d_hn, alpha_dev=alpha_dev)
         else:
             ops.gemm(GEMM_NN, dlogits, self._view("emb"), d_hn, alpha_dev=alpha_dev)

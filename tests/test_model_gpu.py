@@ -290,7 +290,7 @@ def test_bf16_mfma_shaped_model_matches_oracle(transposed_copies):
     loss = compute_loss(dbatch, model, CEWithChunkedOutputLoss())
     loss.backward()
     assert abs(loss.item() - ref.item()) <= 1e-2 * abs(ref.item())
-    assert (model._flat_t is not None) == transposed_copies
+    assert ("emb" in model._wt) == transposed_copies and (len(model._wt) == (0 if not transposed_copies else 1 + 4 * 2))
     if transposed_copies:
         for name in ("emb", "L0.wqkv", "L1.w2"):
             assert torch.equal(model._view_t(name), model._view(name).t())
