@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define SSI_ABI_VERSION 3 /* 2: + ssi_attn_varlen_fwd/bwd(_rope), ssi_set_gemm_tile_order, NN form of ssi_gemm_swiglu_bwd
-                           * 3: ssi_ce_reduce takes `vocab` and reports out-of-range labels in out[3] */
+                           * 3: ssi_ce_reduce takes `vocab` and reports out-of-range labels in out[3]; + ssi_doc_ranges */
 
 enum { SSI_F32 = 0, SSI_BF16 = 1 };
 enum { SSI_OK = 0, SSI_ERR_ARG = 1, SSI_ERR_UNSUPPORTED = 2, SSI_ERR_WORKSPACE = 3, SSI_ERR_HIP = 1000 /* + hipError_t */ };
@@ -110,6 +110,12 @@ int ssi_attn_varlen_fwd(const void* qkv, int64_t ld, void* out, float* lse, cons
 int ssi_attn_varlen_bwd(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
                         float* delta, const int32_t* doc_start, const int32_t* doc_end, int64_t batch, int64_t seq,
                         int n_heads, int n_kv, int head_dim, int dtype, void* stream);
+
+/* input_pos [batch, seq] (int64; restarts at 0 with every document of a packed row) -> the int32 [batch*seq] arrays the varlen entries
+ * take: positions (clamped to [0, max_pos]: the RoPE table is never indexed past its end), doc_start, doc_end.  Position 0 of a row
+ * always starts a document.  One launch (the reference has no packed path: ssi/data/__init__.py:66-73 raises). */
+int ssi_doc_ranges(const int64_t* input_pos, int64_t batch, int64_t seq, int64_t max_pos, int32_t* positions, int32_t* doc_start,
+                   int32_t* doc_end, void* stream);
 
 /* Same, followed by the backward of the RoPE rotation on the q and k heads of dqkv (= ssi_rope_inplace(dqkv, ..., inverse=1)): the
  * MFMA kernels apply it in their epilogues, which saves a pass over dqkv.  rope_table / table_len / positions as in ssi_rope_inplace. */

@@ -467,6 +467,59 @@ extern "C" int ssi_count_tokens(const int64_t* tokens, const int64_t* labels, in
 }
 
 // =====================================================================================================================
+// Packed rows: positions + document bounds from input_pos in ONE launch (the model did this with ~10 torch ops per step).
+// One 256-thread workgroup per row; a document starts where input_pos == 0 (and at position 0 of the row).  Each thread owns a
+// contiguous span: last start at or before it (forward) and first start after it (backward) come from two LDS scans over the
+// per-thread summaries, then the span is filled.  Integer work: results are exact.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void doc_ranges_kernel(const int64_t* __restrict__ input_pos, int64_t seq, int max_pos,
+                                                         int32_t* __restrict__ pos, int32_t* __restrict__ doc_start,
+                                                         int32_t* __restrict__ doc_end) {
+    __shared__ int last_start[256], first_start[256];
+    const int64_t row = blockIdx.x;
+    const int64_t* ip = input_pos + row * seq;
+    const int t = threadIdx.x;
+    const int span = (int)((seq + 255) / 256);
+    const int lo = t * span, hi = (int)(lo + span < seq ? lo + span : seq);
+    int ls = -1, fs = (int)seq;  // last start inside my span, first start inside my span
+    for (int s = lo; s < hi; ++s) {
+        const bool st = s == 0 || ip[s] == 0;
+        if (st) { ls = s; if (fs == (int)seq) fs = s; }
+    }
+    last_start[t] = ls;
+    first_start[t] = fs;
+    __syncthreads();
+    int before = -1;             // last start in the spans before mine
+    for (int u = t - 1; u >= 0 && before < 0; --u) before = last_start[u];
+    int after = (int)seq;        // first start in the spans after mine
+    for (int u = t + 1; u < 256 && after == (int)seq; ++u) after = first_start[u];
+    // forward: document start of every position of my span
+    int cur = before;
+    for (int s = lo; s < hi; ++s) {
+        if (s == 0 || ip[s] == 0) cur = s;
+        doc_start[row * seq + s] = cur;
+        const int64_t p = ip[s];
+        pos[row * seq + s] = (int32_t)(p < 0 ? 0 : (p > max_pos ? max_pos : p));
+    }
+    // backward: one past the last position of the document = the first start strictly after s
+    int nxt = after;
+    for (int s = hi - 1; s >= lo; --s) {
+        doc_end[row * seq + s] = nxt;
+        if (s == 0 || ip[s] == 0) nxt = s;
+    }
+}
+
+extern "C" int ssi_doc_ranges(const int64_t* input_pos, int64_t batch, int64_t seq, int64_t max_pos, int32_t* positions,
+                              int32_t* doc_start, int32_t* doc_end, void* stream) {
+    SSI_CHECK_ARG(input_pos && positions && doc_start && doc_end && batch >= 0 && seq >= 0 && seq < (1LL << 31) && max_pos >= 0 && max_pos < (1LL << 31));
+    if (batch == 0 || seq == 0) return SSI_OK;
+    hipLaunchKernelGGL(doc_ranges_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, input_pos, seq, (int)max_pos, positions,
+                       doc_start, doc_end);
+    SSI_LAUNCH_CHECK();
+    return SSI_OK;
+}
+
+// =====================================================================================================================
 // K11 scale_grads, K12 sum of squares (for clip_grad_norm_), K13 AdamW — flat-buffer streaming kernels
 // =====================================================================================================================
 template <typename T>

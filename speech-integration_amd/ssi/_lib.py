@@ -44,6 +44,7 @@ PROTOTYPES = {
     "ssi_attn_varlen_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_int, _P]),
     "ssi_attn_varlen_bwd_rope": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int, c_int, c_int,
                                          c_int, _P]),
+    "ssi_doc_ranges": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P, _P]),
     "ssi_swiglu_fwd": (c_int, [_P, _P, c_int64, c_int64, c_int, _P]),
     "ssi_swiglu_bwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P]),
     "ssi_gemm": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_float, _P,

@@ -323,7 +323,8 @@ class HipLlamaDecoder(nn.Module):
     # ---- forward: decoder stack --------------------------------------------------------------------------------------
     @staticmethod
     def _document_ranges(input_pos: Tensor, max_pos: Optional[int] = None) -> tuple[Tensor, Tensor, Tensor]:
-        """Packed rows (torchtune ``PackedDataset``: ``input_pos`` restarts at 0 with every document of a row) -> int32 [B*S]
+        """Torch restatement of ``ops.doc_ranges`` (kept as the checker of that kernel's test; the forward uses the kernel).
+        Packed rows (torchtune ``PackedDataset``: ``input_pos`` restarts at 0 with every document of a row) -> int32 [B*S]
         (positions, doc_start, doc_end): a query attends to the keys doc_start <= key <= query of its own row, which is the
         block-causal mask ``padded_collate_packed`` builds from ``seq_lens``.  The padding tail of a pack continues the last
         document's positions and so joins it: no real query sees those keys (causal) and their labels are ignored."""
@@ -348,7 +349,7 @@ class HipLlamaDecoder(nn.Module):
                 raise ValueError("input_pos exceeds the RoPE cache")
             # device tensor: no blocking read-back in the step; positions are clamped to the cache instead (the data layer bounds
             # them by tokenizer.max_seq_len <= rope cache, ssi/data/packed.py), so the kernels never index past the table
-            pos, ds, de = self._document_ranges(input_pos.to(tokens.device), self._rope.shape[0] - 1)
+            pos, ds, de = ops.doc_ranges(input_pos.to(tokens.device), self._rope.shape[0] - 1)  # one launch (was ~10 torch ops)
         T, D, I = B * S, self.embed_dim, self.intermediate_dim
         H, KV, hd, dt, A = self.num_heads, self.num_kv_heads, self.head_dim, self.dtype, self._arena
         if S > self._rope.shape[0]:

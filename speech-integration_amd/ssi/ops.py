@@ -10,7 +10,7 @@ from torch import Tensor
 from . import _lib
 from ._lib import GEMM_NN, GEMM_NT, GEMM_TN, check, dtype_code, ptr, stream_ptr
 
-__all__ = ["embed_fwd", "embed_bwd", "rmsnorm_fwd", "rmsnorm_bwd", "rope_", "attn_fwd", "attn_bwd", "swiglu_fwd",
+__all__ = ["doc_ranges", "embed_fwd", "embed_bwd", "rmsnorm_fwd", "rmsnorm_bwd", "rope_", "attn_fwd", "attn_bwd", "swiglu_fwd",
            "swiglu_bwd", "gemm", "gemm_splitk", "splitk_choice", "gemm_swiglu_fwd", "gemm_swiglu_bwd", "transpose", "ce_fwd", "ce_reduce", "count_tokens", "scale_", "sumsq", "adamw_step", "set_impl",
            "GEMM_NT", "GEMM_NN", "GEMM_TN"]
 
@@ -101,6 +101,16 @@ def _doc_ptrs(doc_start: Optional[Tensor], doc_end: Optional[Tensor], rows: int)
     for t in (doc_start, doc_end):
         assert t.dtype == torch.int32 and t.is_contiguous() and t.numel() == rows
     return ptr(doc_start), ptr(doc_end)
+
+
+def doc_ranges(input_pos: Tensor, max_pos: int) -> tuple[Tensor, Tensor, Tensor]:
+    """Packed rows: int32 [B*S] (positions clamped to max_pos, doc_start, doc_end) from input_pos [B, S] in one launch."""
+    assert input_pos.dim() == 2 and input_pos.dtype == torch.int64
+    ip = input_pos.contiguous()
+    B, S = ip.shape
+    out = torch.empty(3, B * S, dtype=torch.int32, device=ip.device)
+    check(_lib.load().ssi_doc_ranges(ptr(ip), B, S, int(max_pos), ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()), "ssi_doc_ranges")
+    return out[0], out[1], out[2]
 
 
 def set_gemm_tile_order(dynamic: bool) -> None:

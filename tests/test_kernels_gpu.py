@@ -782,3 +782,27 @@ def test_qkv_gemm_with_rope_in_the_epilogue_equals_gemm_then_rope(ops, explicit_
     finally:
         ops.set_impl(prev)
     torch.testing.assert_close(out3.float(), ref.float(), rtol=2e-2, atol=2e-2)
+
+
+def test_doc_ranges_kernel_matches_the_torch_restatement(ops):
+    """Packed rows: positions / doc_start / doc_end from input_pos in one launch — bit-exact against the torch ops the model used
+    before, on rows with 1-token documents, a document crossing every 256-thread span boundary, S not a multiple of anything."""
+    from ssi.model import HipLlamaDecoder
+    g = torch.Generator().manual_seed(130)
+    for B, S in ((1, 1), (2, 37), (3, 300), (2, 8192), (1, 5000)):
+        rows = []
+        for _ in range(B):
+            lens, left = [], S
+            while left > 0:
+                n = min(left, int(torch.randint(1, max(2, S // 3), (1,), generator=g)))
+                lens.append(n)
+                left -= n
+            rows.append(torch.cat([torch.arange(n) for n in lens]))
+        ip = torch.stack(rows).to(torch.int64)
+        ip[0, 0] = 5  # a row whose first position is not 0 still starts a document there
+        pos, ds, de = ops.doc_ranges(ip.to(DEV), 4095)
+        rpos, rds, rde = HipLlamaDecoder._document_ranges(ip, 4095)
+        assert torch.equal(pos.cpu(), rpos) and torch.equal(ds.cpu(), rds) and torch.equal(de.cpu(), rde), (B, S)
+    big = torch.arange(6000).reshape(1, 6000)
+    pos, _, _ = ops.doc_ranges(big.to(DEV), 4095)
+    assert int(pos.max()) == 4095   # clamped to the RoPE table
