@@ -787,7 +787,6 @@ __device__ __forceinline__ void nt4_body(char* smem, int tiles_m, int tiles_n, i
         }
     };
     auto dma_body = [&](auto cur_c, auto first) {
-        static_assert(!(DMA && SPLITK), "the LDS-DMA loop has no split-K instantiation (it spills)");
         constexpr int cur = decltype(cur_c)::value;
         if (A_COL) asm volatile("" : "+v"(trA));  // keep the per-read XOR of the transposed-read addresses from being hoisted into 16 registers
         if (B_COL) asm volatile("" : "+v"(trB));
@@ -811,11 +810,14 @@ __device__ __forceinline__ void nt4_body(char* smem, int tiles_m, int tiles_n, i
             if (m >= A0 - 1 && m < A0 - 1 + NA * SA && (m - (A0 - 1)) % SA == 0) dma_m0(cur, (m - (A0 - 1)) / SA);
             if (m >= A0 && m < A0 + NA * SA && (m - A0) % SA == 0) dma_go((m - A0) / SA);
         });
+        // the fetch cursor moves on BETWEEN the phases (this K-step's buffer resources were taken at the barrier above).  Not inside the
+        // unrolled MFMA loops: with the split-K unit arithmetic (integer divisions) inlined there, the 64-iteration loop passes hipcc's
+        // size limit for `#pragma unroll`, stays a runtime loop, and the accumulator array it then indexes dynamically lands in scratch
+        advance();
         phase(F1A, F1B, F_{}, [&](int m) {
             if (m >= 2 && m < 2 + 5 * (16 - NA) && (m - 2) % 5 == 0) dma_m0(cur, NA + (m - 2) / 5);  // 2, 7, ...
             if (m >= 3 && m < 3 + 5 * (16 - NA) && (m - 3) % 5 == 0) dma_go(NA + (m - 3) / 5);       // 3, 8, ...
             if (m == 11) {
-                advance();
                 // K-step +1 (16 pieces issued during the last K-step) has landed for this wave — the NA + 2 pieces of this K-step issued so
                 // far may still be in flight — and, with the barrier, for every wave
                 if constexpr (NA == 4) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
@@ -1320,8 +1322,7 @@ int ssi_gemm_mfma_bf16_splitk(int layout, int64_t M, int64_t N, int64_t K, const
     auto st = (hipStream_t)stream;
     // weight-gradient form on the persistent kernel: units = tile x K-slice, every slice at least 6 K-steps, no residual
     if (layout == SSI_GEMM_TN && nt4_ok(K) && nt4_ld_ok(lda, ldb) && !R && K / BK / splits >= 6 && ldc % 8 == 0) {
-        // (register-staged loop: the LDS-DMA loop's split-K instantiation spills under hipcc 7.2 — 1100 scratch accesses — and is not used)
-        if (int rc = launch_nt4<true, true, EPI_PLAIN, 0, true, false>(tm, tn, K, A, lda, B, ldb, C, ldc, nullptr, 1.f, nullptr, st,
+        if (int rc = launch_nt4<true, true, EPI_PLAIN, 0, true, TN_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, nullptr, 1.f, nullptr, st,
                                                                  EpiArgs{nullptr, 0, nullptr, 0, 0}, splits, slabs)) return rc;
         hipLaunchKernelGGL(nt4_splitk_reduce_kernel, dim3((unsigned)ssi_cdiv((int64_t)tm * tn * 64, 4)), dim3(256), 0, st, slabs, splits, tm, tn,
                            (bf16_t*)C, ldc, alpha, alpha_dev, accumulate);
