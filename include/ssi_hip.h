@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define SSI_ABI_VERSION 3 /* 2: + ssi_attn_varlen_fwd/bwd(_rope), ssi_set_gemm_tile_order, NN form of ssi_gemm_swiglu_bwd
-                           * 3: ssi_ce_reduce takes `vocab` and reports out-of-range labels in out[3]; + ssi_doc_ranges */
+                           * 3: ssi_ce_reduce takes `vocab` and reports out-of-range labels in out[3]; + ssi_doc_ranges; ssi_rmsnorm_bwd takes accumulate_dscale */
 
 enum { SSI_F32 = 0, SSI_BF16 = 1 };
 enum { SSI_OK = 0, SSI_ERR_ARG = 1, SSI_ERR_UNSUPPORTED = 2, SSI_ERR_WORKSPACE = 3, SSI_ERR_HIP = 1000 /* + hipError_t */ };
@@ -69,12 +69,13 @@ int ssi_embed_bwd(const int64_t* tokens, const void* dout, void* dtable, int64_t
 /* y = (x32 * rsqrt(mean(x32^2)+eps)).to(dtype) * scale ; rstd[row] saved for backward */
 int ssi_rmsnorm_fwd(const void* x, const void* scale, void* y, float* rstd, int64_t rows, int64_t dim, float eps,
                     int dtype, void* stream);
-/* dx = d(rmsnorm)/dx . dy (+ dres if non-null);  dscale += sum_rows dy * xhat  (two-stage deterministic reduce).
+/* dx = d(rmsnorm)/dx . dy (+ dres if non-null);  dscale (+)= sum_rows dy * xhat  (two-stage deterministic reduce; accumulate_dscale
+ * == 0 overwrites: the first micro-batch of an accumulation window writes the gradients, nothing zeroes them beforehand).
  * partials: fp32 workspace of ssi_rmsnorm_bwd_workspace_bytes(rows, dim) bytes. */
 int64_t ssi_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t dim);
 int ssi_rmsnorm_bwd(const void* dy, const void* x, const void* scale, const float* rstd, const void* dres, void* dx,
-                    void* dscale, int64_t rows, int64_t dim, int dtype, void* workspace, int64_t workspace_bytes,
-                    void* stream);
+                    void* dscale, int accumulate_dscale, int64_t rows, int64_t dim, int dtype, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 
 /* ---- K4  Llama3ScaledRoPE (adjacent-pair rotation, fp32 math; torchtune MultiHeadAttention.pos_embeddings) -------- */
 /* x: [rows, ld] rows = b*seq_len + s; rotates heads [0, n_heads_rot) of width head_dim in place; position of a row is

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
 // much as the 60x larger rmsnorm_bwd pass in front of it).
 template <typename T>
 __global__ __launch_bounds__(1024) void colsum_accum_kernel(const float* __restrict__ partials, T* __restrict__ dscale,
-                                                            int nblocks, int dim) {
+                                                            int nblocks, int dim, int accumulate) {
     __shared__ float red[16][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cx;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(1024) void colsum_accum_kernel(const float* __restr
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += red[r][cx];
-        dscale[col] = from_f32<T>(to_f32<T>(dscale[col]) + t);
+        dscale[col] = from_f32<T>(accumulate ? to_f32<T>(dscale[col]) + t : t);
     }
 }
 
@@ -258,7 +258,7 @@ extern "C" int ssi_rmsnorm_fwd(const void* x, const void* scale, void* y, float*
 
 template <typename T>
 static int launch_rmsnorm_bwd(const T* dy, const T* x, const T* scale, const float* rstd, const T* dres, T* dx, T* dscale,
-                              int64_t rows, int dim, int nb, size_t lds_bytes, float* workspace, hipStream_t st) {
+                              int64_t rows, int dim, int nb, size_t lds_bytes, float* workspace, hipStream_t st, int accumulate) {
     const int64_t vec_per_lane = ssi_cdiv(dim / Vec16<T>::N, 64);
     if (vec_per_lane <= 1)
         hipLaunchKernelGGL((rmsnorm_bwd_kernel<T, 1>), dim3(nb), dim3(256), lds_bytes, st, dy, x, scale, rstd, dres, dx, workspace, rows, dim);
@@ -270,12 +270,12 @@ static int launch_rmsnorm_bwd(const T* dy, const T* x, const T* scale, const flo
         hipLaunchKernelGGL((rmsnorm_bwd_kernel<T, 8>), dim3(nb), dim3(256), lds_bytes, st, dy, x, scale, rstd, dres, dx, workspace, rows, dim);
     else { ssi_set_error("rmsnorm_bwd: dim %d too large", dim); return SSI_ERR_UNSUPPORTED; }
     SSI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_accum_kernel<T>, dim3((unsigned)ssi_cdiv(dim, 64)), dim3(1024), 0, st, (const float*)workspace, dscale, nb, dim);
+    hipLaunchKernelGGL(colsum_accum_kernel<T>, dim3((unsigned)ssi_cdiv(dim, 64)), dim3(1024), 0, st, (const float*)workspace, dscale, nb, dim, accumulate);
     return SSI_OK;
 }
 
 extern "C" int ssi_rmsnorm_bwd(const void* dy, const void* x, const void* scale, const float* rstd, const void* dres,
-                               void* dx, void* dscale, int64_t rows, int64_t dim, int dtype, void* workspace,
+                               void* dx, void* dscale, int accumulate_dscale, int64_t rows, int64_t dim, int dtype, void* workspace,
                                int64_t workspace_bytes, void* stream) {
     SSI_CHECK_ARG(dy && x && scale && rstd && dx && dscale && rows >= 0 && dim > 0 && dim % 8 == 0);
     if (rows == 0) return SSI_OK;
@@ -289,7 +289,7 @@ extern "C" int ssi_rmsnorm_bwd(const void* dy, const void* x, const void* scale,
     int rc = SSI_OK;
     SSI_DISPATCH_DTYPE(dtype, rc = launch_rmsnorm_bwd<T>((const T*)dy, (const T*)x, (const T*)scale, rstd, (const T*)dres,
                                                          (T*)dx, (T*)dscale, rows, (int)dim, nb, lds_bytes,
-                                                         (float*)workspace, (hipStream_t)stream));
+                                                         (float*)workspace, (hipStream_t)stream, accumulate_dscale));
     if (rc) return rc;
     SSI_LAUNCH_CHECK();
     return SSI_OK;

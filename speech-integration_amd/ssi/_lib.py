@@ -33,7 +33,7 @@ PROTOTYPES = {
     "ssi_embed_bwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, _P, c_int64, _P]),
     "ssi_rmsnorm_fwd": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_float, c_int, _P]),
     "ssi_rmsnorm_bwd_workspace_bytes": (c_int64, [c_int64, c_int64]),
-    "ssi_rmsnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P]),
+    "ssi_rmsnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int64, c_int, _P, c_int64, _P]),
     "ssi_rope_inplace": (c_int, [_P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, _P, c_int, c_int, _P]),
     "ssi_gemm_rope": (c_int, [c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P, c_int64, _P,
                               c_int, _P]),

@@ -218,7 +218,13 @@ class HipLlamaDecoder(nn.Module):
         self._saved: Optional[dict] = None       # activations of the forward awaiting its backward
         self._fwd_generation = 0
         self.pending_grad_scale: Optional[Tensor] = None  # lazy scale_grads (device fp32 scalar), consumed by the optimizer
+        # Gradient buffer protocol: nothing zeroes the 2.5 GB buffer between optimizer steps.  `_grads_dirty` = the buffer holds the
+        # gradients of this accumulation window, the next backward ADDS; not dirty = the next backward WRITES every element (weight
+        # gradients by the GEMM's plain epilogue, norm scales by assignment, the tied embedding by the head's weight gradient before the
+        # scatter-add), so whatever is in the buffer (`_grads_stale`: left-overs of the last window) never has to be cleared.
         self._grads_dirty = False
+        self._grads_stale = False
+        self._emb_grad_written = False
         self.label_errors: Optional[Tensor] = None        # device count of out-of-range labels seen by the last fused loss
         self.grad_sync = None                             # optional ssi.distributed.GradSync
         self.sync_this_backward = False
@@ -292,14 +298,24 @@ class HipLlamaDecoder(nn.Module):
             if p.grad is None:
                 p.grad = self._view(name, rows, self._flat_grad)
 
+    # SSI_ZERO_GRADS=1 (A/B runs): the round-1 protocol — AdamW zeroes the buffer in its pass and every backward accumulates
+    always_accumulate = os.environ.get("SSI_ZERO_GRADS", "0") == "1"
+
     def zero_grad(self, set_to_none: bool = True) -> None:
-        if self._grads_dirty:  # the fused optimizer step already zeroes the buffer in its own pass
-            self._flat_grad.zero_()
-            self._grads_dirty = False
-        self.pending_grad_scale = None
-        if set_to_none:
+        """With ``set_to_none`` (torch's default) no memory is touched: the next backward overwrites the buffer.  Only a caller who
+        keeps the ``p.grad`` views and wants to read zeros pays for a memset."""
+        if set_to_none and not self.always_accumulate:
+            self._grads_stale = self._grads_stale or self._grads_dirty
             for p, _, _ in self._param_src:
                 p.grad = None
+        elif self._grads_dirty or self._grads_stale:
+            self._flat_grad.zero_()
+            self._grads_stale = False
+        if set_to_none and self.always_accumulate:
+            for p, _, _ in self._param_src:
+                p.grad = None
+        self._grads_dirty = False
+        self.pending_grad_scale = None
 
     def activation_bytes(self) -> int:
         return self._arena.bytes()
@@ -401,7 +417,7 @@ class HipLlamaDecoder(nn.Module):
         H, KV, hd, dt, A = self.num_heads, self.num_kv_heads, self.head_dim, self.dtype, self._arena
         L = self.num_layers
         G = self._flat_grad
-        self._grads_dirty = True
+        acc = self._grads_dirty or self.always_accumulate  # False: first backward of the window, every gradient is written, not added
         gv = lambda name: self._view(name, None, G)  # noqa: E731
         ws = A.get("ws.rms", (max(ops.rmsnorm_bwd_workspace_bytes(T, D), 16),), torch.uint8)
 
@@ -411,9 +427,9 @@ class HipLlamaDecoder(nn.Module):
             splits = ops.splitk_choice(g.shape[0], g.shape[1], T) if (dt == torch.bfloat16 and T % 64 == 0) else 1
             if splits > 1:
                 wsk = A.get("ws.splitk", (splits * g.shape[0] * g.shape[1],), torch.float32)
-                ops.gemm_splitk(GEMM_TN, dy, x, g, splits, wsk, accumulate=True)
+                ops.gemm_splitk(GEMM_TN, dy, x, g, splits, wsk, accumulate=acc)
             else:
-                ops.gemm(GEMM_TN, dy, x, g, accumulate=True)
+                ops.gemm(GEMM_TN, dy, x, g, accumulate=acc)
 
         sync = self.grad_sync if (self.grad_sync is not None and self.sync_this_backward) else None
         self._ensure_transposed()
@@ -427,7 +443,7 @@ class HipLlamaDecoder(nn.Module):
 
         dh = A.get("dh.a", (T, D), dt)
         ops.rmsnorm_bwd(d_hn, A.get(f"h{L}", (T, D), dt), self.norm.scale, A.get("rstdf", (T,), torch.float32), None, dh,
-                        gv("norm"), ws)
+                        gv("norm"), ws, accumulate=acc)
         if sync:
             sync.bucket_ready(*self.buckets[0])
         for l in reversed(range(L)):
@@ -447,7 +463,7 @@ class HipLlamaDecoder(nn.Module):
             wgrad(dgu, xn2, f"L{l}.w13")
             dhmid = A.get("dh.b", (T, D), dt)
             ops.rmsnorm_bwd(dxn, hmid, self._view(f"L{l}.mlp_norm"), A.get(f"rstd2.{l}", (T,), torch.float32), dh, dhmid,
-                            gv(f"L{l}.mlp_norm"), ws)
+                            gv(f"L{l}.mlp_norm"), ws, accumulate=acc)
             # attention: hmid = h_in + att @ wo^T
             datt = A.get("datt", (T, H * hd), dt)
             dgrad(dhmid, f"L{l}.wo", datt)
@@ -460,11 +476,14 @@ class HipLlamaDecoder(nn.Module):
             dgrad(dqkv, f"L{l}.wqkv", dxn)
             wgrad(dqkv, xn1, f"L{l}.wqkv")
             ops.rmsnorm_bwd(dxn, h_in, self._view(f"L{l}.sa_norm"), A.get(f"rstd1.{l}", (T,), torch.float32), dhmid, dh,
-                            gv(f"L{l}.sa_norm"), ws)
+                            gv(f"L{l}.sa_norm"), ws, accumulate=acc)
             if sync:
                 sync.bucket_ready(*self.buckets[1 + (L - 1 - l)])
         ws_e = A.get("ws.emb", (max(_lib.load().ssi_embed_bwd_workspace_bytes(self.vocab_size), 16),), torch.uint8)
+        if not acc and not self._emb_grad_written:  # backward through the hidden states only (no tied head in front): the scatter-add
+            gv("emb").zero_()                       # below touches only the rows of this batch's tokens
         ops.embed_bwd(tok, dh, gv("emb"), self.vocab_size, ws_e)
+        self._grads_dirty, self._grads_stale, self._emb_grad_written = True, False, False
         if sync:
             sync.bucket_ready(*self.buckets[-1])
         self._saved = None
@@ -485,14 +504,15 @@ class HipLlamaDecoder(nn.Module):
     def _head_backward(self, dlogits: Tensor, hn: Tensor, alpha_dev: Optional[Tensor]) -> Tensor:
         """d_hn = alpha * dlogits @ E ;  dE += alpha * dlogits^T @ hn   (dlogits: [T, vocab_pad], pad columns zero)."""
         T, D = hn.shape
-        self._grads_dirty = True
+        acc = self._grads_dirty or self.always_accumulate
         d_hn = self._arena.get("d_hn", (T, D), self.dtype)
         self._ensure_transposed()
         if self._has_t("emb"):
             ops.gemm(GEMM_NT, dlogits, self._view_t("emb"), d_hn, alpha_dev=alpha_dev)
         else:
             ops.gemm(GEMM_NN, dlogits, self._view("emb"), d_hn, alpha_dev=alpha_dev)
-        ops.gemm(GEMM_TN, dlogits, hn, self._view("emb", None, self._flat_grad), alpha_dev=alpha_dev, accumulate=True)
+        ops.gemm(GEMM_TN, dlogits, hn, self._view("emb", None, self._flat_grad), alpha_dev=alpha_dev, accumulate=acc)
+        self._emb_grad_written = True  # the decoder backward that follows adds the token rows on top and closes the window
         return d_hn
 
     # ---- public API --------------------------------------------------------------------------------------------------

@@ -56,7 +56,7 @@ def rmsnorm_bwd_workspace_bytes(rows: int, dim: int) -> int:
 
 
 def rmsnorm_bwd(dy: Tensor, x: Tensor, scale: Tensor, rstd: Tensor, dres: Tensor | None, dx: Tensor, dscale: Tensor,
-                workspace: Tensor | None = None) -> None:
+                workspace: Tensor | None = None, accumulate: bool = True) -> None:
     lib = _lib.load()
     dim = x.shape[-1]
     rows = x.numel() // dim
@@ -65,7 +65,7 @@ def rmsnorm_bwd(dy: Tensor, x: Tensor, scale: Tensor, rstd: Tensor, dres: Tensor
     need = lib.ssi_rmsnorm_bwd_workspace_bytes(rows, dim)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = _byte_ws(need, dy)
-    check(lib.ssi_rmsnorm_bwd(ptr(dy), ptr(x), ptr(scale), ptr(rstd), ptr(dres), ptr(dx), ptr(dscale), rows, dim,
+    check(lib.ssi_rmsnorm_bwd(ptr(dy), ptr(x), ptr(scale), ptr(rstd), ptr(dres), ptr(dx), ptr(dscale), int(accumulate), rows, dim,
                               dtype_code(x.dtype), ptr(workspace), workspace.numel() * workspace.element_size(),
                               stream_ptr()), "ssi_rmsnorm_bwd")
 

@@ -4,7 +4,8 @@
 ``torch.optim.Optimizer`` (so ``LambdaLR``, ``param_groups``, ``state_dict`` work unchanged) whose ``step`` is ONE HIP
 kernel over the model's flat parameter / gradient / moment buffers: decoupled weight decay, fp32 op-math, a single
 rounding on store — the semantics of ``torch.optim.AdamW(fused=True)`` (K13), with ``scale_grads`` (K11) and the
-clip coefficient (K12) folded in as a device-side gradient multiplier and the gradient buffer zeroed in the same pass."""
+clip coefficient (K12) folded in as a device-side gradient multiplier.  The gradient buffer is not zeroed: the first backward of the
+next accumulation window overwrites it (``HipLlamaDecoder`` gradient-buffer protocol)."""
 
 from __future__ import annotations
 
@@ -59,7 +60,7 @@ class HipAdamW(torch.optim.Optimizer):
             if hi > lo:
                 ops.adamw_step(m._flat[lo:hi], m._flat_grad[lo:hi], self._exp_avg[lo:hi], self._exp_avg_sq[lo:hi], lr=float(g["lr"]),
                                beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
-                               step=self._step_count, grad_scale_dev=m.pending_grad_scale, zero_grad=True)
+                               step=self._step_count, grad_scale_dev=m.pending_grad_scale, zero_grad=m.always_accumulate)
 
         sync = getattr(m, "grad_sync", None)
         tail = sync.deferred_range() if sync is not None and hasattr(sync, "deferred_range") else None
@@ -73,7 +74,8 @@ class HipAdamW(torch.optim.Optimizer):
             sync.finish_deferred()
             update(lo, hi)
         m.pending_grad_scale = None
-        m._grads_dirty = False
+        # the gradients are NOT zeroed (2.5 GB of writes per step for nothing): the next backward overwrites them (model protocol)
+        m._grads_dirty, m._grads_stale = False, not m.always_accumulate
         m._hip_epoch += 1  # weights changed behind torch's version counter
         if self._views_ready:
             for st in self.state.values():
@@ -81,7 +83,7 @@ class HipAdamW(torch.optim.Optimizer):
         return loss
 
     def zero_grad(self, set_to_none: bool = True) -> None:
-        # the fused step already zeroed the buffer when it ran; zero again only if gradients are pending
+        # nothing to clear after a step (the next backward overwrites the buffer); the model zeroes only for set_to_none=False
         sync = getattr(self.model, "grad_sync", None)
         if sync is not None and hasattr(sync, "finish_deferred"):
             sync.finish_deferred()  # a step that was skipped must not zero under a reduction in flight

@@ -76,11 +76,21 @@ def test_fp32_model_matches_golden_forward_backward_step(name, golden_dir):
     scale_grads(model, torch.tensor(1 / n))
     opt.step()
     opt.zero_grad(set_to_none=True)
-    assert all(p.grad is None for p in model.parameters()) and float(model._flat_grad.abs().max()) == 0.0
+    # nothing zeroes the gradient buffer: the next backward overwrites it (and must reproduce the gradients of a fresh model)
+    assert all(p.grad is None for p in model.parameters()) and model._grads_stale and not model._grads_dirty
     for key, p in model.named_parameters():
         if "after/" + key in g.files:
             got = p.detach().cpu().reshape(-1, p.shape[-1])[:4, :16].numpy() if p.dim() > 1 else p.detach().cpu()[:16].numpy()
             np.testing.assert_allclose(got, g["after/" + key], rtol=0, atol=5e-6, err_msg=key)
+    stale = model._flat_grad.clone()
+    assert float(stale.abs().max()) > 0
+    (compute_loss(dbatch, model, loss_fn) * n).backward()          # first backward of the new window: writes, does not add
+    g_new = model._flat_grad.clone()
+    model.zero_grad(set_to_none=False)                              # the explicit form does clear the buffer
+    assert float(model._flat_grad.abs().max()) == 0.0
+    (compute_loss(dbatch, model, loss_fn) * n).backward()
+    assert torch.equal(model._flat_grad, g_new), "a backward over left-over gradients must equal one over zeros"
+    model.zero_grad()
     # optimizer state dict is torch-AdamW shaped and round-trips
     sd_opt = opt.state_dict()
     assert set(sd_opt["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd_opt["state"][0]["step"]) == 1.0
