@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define SSI_ABI_VERSION 3 /* 2: + ssi_attn_varlen_fwd/bwd(_rope), ssi_set_gemm_tile_order, NN form of ssi_gemm_swiglu_bwd
-                           * 3: ssi_ce_reduce takes `vocab` and reports out-of-range labels in out[3]; + ssi_doc_ranges; ssi_rmsnorm_bwd takes accumulate_dscale */
+                           * 3: ssi_ce_reduce takes `vocab` and reports out-of-range labels in out[3]; + ssi_doc_ranges; ssi_rmsnorm_bwd takes accumulate_dscale; + ssi_lmhead_ce_fwd/bwd */
 
 enum { SSI_F32 = 0, SSI_BF16 = 1 };
 enum { SSI_OK = 0, SSI_ERR_ARG = 1, SSI_ERR_UNSUPPORTED = 2, SSI_ERR_WORKSPACE = 3, SSI_ERR_HIP = 1000 /* + hipError_t */ };
@@ -174,6 +174,21 @@ int ssi_ce_fwd(void* logits, int64_t ld, const int64_t* labels, int64_t rows, in
  * are not ignored and lie in [0, vocab) — the predicate ssi_ce_fwd uses), out[3] = number of out-of-range labels.  out: 4 floats. */
 int ssi_ce_reduce(const float* row_loss, const int64_t* labels, int64_t rows, int64_t vocab, int64_t ignore_index, float* out,
                   void* stream);
+
+/* ---- K8 + K9 as one entry per direction: tied LM head (TiedLinear over tok_embeddings, ssi/loss.py:8-14) + chunked CE (trainer.py:300) ----
+ * fwd: logits_ws[rows, vocab_pad] = hidden[rows, dim] table[vocab_pad, dim]^T (table rows >= vocab are zero padding), then ssi_ce_fwd
+ *      on it (write_grad: logits_ws becomes softmax - onehot in place) and ssi_ce_reduce into stats[4].  Equals the reference's
+ *      CEWithChunkedOutputLoss(model(tokens), shifted_labels) for any chunk count.
+ * bwd: d_hidden = alpha * dlogits table;  d_table (+)= alpha * dlogits^T hidden   (alpha_dev: device scalar = upstream grad / n_valid).
+ * The [rows, vocab_pad] logits stay in HBM between the two calls (the caller's workspace, 4.37 GB at T = 16 384): recomputing the logit
+ * tiles in backward instead costs another 2 rows vocab_pad dim flop (8.95 TFLOP = 6 ms per step at 1.5 PFLOP/s) to save the 1.8 ms the
+ * register-resident CE kernel takes — measured and decided in DESIGN.md §4. */
+int ssi_lmhead_ce_fwd(const void* hidden, int64_t ldh, const void* table, int64_t ldt, const int64_t* labels, int64_t rows,
+                      int64_t dim, int64_t vocab, int64_t vocab_pad, int64_t ignore_index, void* logits_ws, int64_t ldl,
+                      float* row_loss, float* stats, int write_grad, int dtype, void* stream);
+int ssi_lmhead_ce_bwd(const void* dlogits, int64_t ldl, const void* hidden, int64_t ldh, const void* table, int64_t ldt,
+                      const float* alpha_dev, int64_t rows, int64_t dim, int64_t vocab_pad, void* d_hidden, int64_t lddh,
+                      void* d_table, int64_t lddt, int accumulate_d_table, int dtype, void* stream);
 
 /* ---- K14 count_token_types + valid-label count (ssi/train_utils.py:150-165, ssi/trainer.py:388,391) ---------------- */
 /* ranges: n_ranges inclusive [lo, hi] pairs (device int64).  out[0..n_ranges) = per-range counts,

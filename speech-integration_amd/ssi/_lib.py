@@ -58,6 +58,8 @@ PROTOTYPES = {
     "ssi_transpose": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int, _P]),
     "ssi_ce_fwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, c_int, c_int, _P]),
     "ssi_ce_reduce": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P]),
+    "ssi_lmhead_ce_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P, _P, c_int, c_int, _P]),
+    "ssi_lmhead_ce_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, _P]),
     "ssi_count_tokens": (c_int, [_P, _P, c_int64, _P, c_int, c_int64, c_int64, _P, _P]),
     "ssi_scale_inplace": (c_int, [_P, c_int64, c_float, _P, c_int, _P]),
     "ssi_sumsq_workspace_bytes": (c_int64, [c_int64]),

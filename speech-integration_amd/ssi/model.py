@@ -582,6 +582,9 @@ class HipLlamaDecoder(nn.Module):
         return self._ce_forward(hn, labels, ignore_index, write_grad=False)[0]
 
     def _ce_forward(self, hn: Tensor, labels: Tensor, ignore_index: int, write_grad: bool) -> tuple[Tensor, Tensor, Tensor]:
+        """Tied head + cross-entropy: (mean loss, stats, logits buffer — which holds softmax - onehot when ``write_grad``).  The same
+        three launches as the one-call ABI entry ``ssi_lmhead_ce_fwd`` (``ops.lmhead_ce_fwd``), issued one by one here so that ``bench.py``
+        can time the head GEMM on its own."""
         T = hn.shape[0]
         logits = self._head_logits(hn, "logits" if write_grad else "logits.x")
         row_loss = self._arena.get("row_loss" if write_grad else "row_loss.x", (T,), torch.float32)

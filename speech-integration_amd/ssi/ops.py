@@ -10,7 +10,7 @@ from torch import Tensor
 from . import _lib
 from ._lib import GEMM_NN, GEMM_NT, GEMM_TN, check, dtype_code, ptr, stream_ptr
 
-__all__ = ["doc_ranges", "embed_fwd", "embed_bwd", "rmsnorm_fwd", "rmsnorm_bwd", "rope_", "attn_fwd", "attn_bwd", "swiglu_fwd",
+__all__ = ["lmhead_ce_fwd", "lmhead_ce_bwd", "doc_ranges", "embed_fwd", "embed_bwd", "rmsnorm_fwd", "rmsnorm_bwd", "rope_", "attn_fwd", "attn_bwd", "swiglu_fwd",
            "swiglu_bwd", "gemm", "gemm_splitk", "splitk_choice", "gemm_swiglu_fwd", "gemm_swiglu_bwd", "transpose", "ce_fwd", "ce_reduce", "count_tokens", "scale_", "sumsq", "adamw_step", "set_impl",
            "GEMM_NT", "GEMM_NN", "GEMM_TN"]
 
@@ -261,6 +261,32 @@ def ce_reduce(row_loss: Tensor, labels: Tensor, vocab: int, ignore_index: int, o
     assert out.dtype == torch.float32 and out.numel() >= 4 and labels.is_contiguous()
     check(_lib.load().ssi_ce_reduce(ptr(row_loss), ptr(labels), labels.numel(), vocab, ignore_index, ptr(out), stream_ptr()),
           "ssi_ce_reduce")
+
+
+def lmhead_ce_fwd(hidden: Tensor, table: Tensor, labels: Tensor, vocab: int, ignore_index: int, logits_ws: Tensor, row_loss: Tensor,
+                  stats: Tensor, write_grad: bool) -> None:
+    """Tied LM head + cross-entropy, one ABI call: logits_ws = hidden @ table^T, row losses, stats = (mean, sum, n_valid, n_out_of_range);
+    with write_grad logits_ws holds softmax - onehot afterwards."""
+    rows, dim = hidden.shape
+    vocab_pad = table.shape[0]
+    assert table.shape[1] == dim and logits_ws.shape == (rows, vocab_pad) and hidden.stride(1) == 1 and table.stride(1) == 1
+    assert labels.dtype == torch.int64 and labels.is_contiguous() and labels.numel() == rows and stats.dtype == torch.float32 and stats.numel() >= 4
+    assert row_loss.dtype == torch.float32 and row_loss.numel() >= rows and hidden.dtype == table.dtype == logits_ws.dtype
+    check(_lib.load().ssi_lmhead_ce_fwd(ptr(hidden), hidden.stride(0), ptr(table), table.stride(0), ptr(labels), rows, dim, vocab, vocab_pad,
+                                        ignore_index, ptr(logits_ws), logits_ws.stride(0), ptr(row_loss), ptr(stats), int(write_grad),
+                                        dtype_code(hidden.dtype), stream_ptr()), "ssi_lmhead_ce_fwd")
+
+
+def lmhead_ce_bwd(dlogits: Tensor, hidden: Tensor, table: Tensor, alpha_dev: Tensor | None, d_hidden: Tensor, d_table: Tensor,
+                  accumulate_d_table: bool) -> None:
+    """d_hidden = alpha * dlogits @ table;  d_table (+)= alpha * dlogits^T @ hidden."""
+    rows, dim = hidden.shape
+    vocab_pad = table.shape[0]
+    assert dlogits.shape == (rows, vocab_pad) and d_hidden.shape == hidden.shape and d_table.shape == table.shape
+    assert alpha_dev is None or (alpha_dev.dtype == torch.float32 and alpha_dev.numel() == 1)
+    check(_lib.load().ssi_lmhead_ce_bwd(ptr(dlogits), dlogits.stride(0), ptr(hidden), hidden.stride(0), ptr(table), table.stride(0),
+                                        ptr(alpha_dev), rows, dim, vocab_pad, ptr(d_hidden), d_hidden.stride(0), ptr(d_table),
+                                        d_table.stride(0), int(accumulate_d_table), dtype_code(hidden.dtype), stream_ptr()), "ssi_lmhead_ce_bwd")
 
 
 def count_tokens(tokens: Tensor, labels: Tensor | None, ranges: Tensor, pad_id: int, ignore_index: int, out: Tensor) -> None:

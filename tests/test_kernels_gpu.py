@@ -806,3 +806,43 @@ def test_doc_ranges_kernel_matches_the_torch_restatement(ops):
     big = torch.arange(6000).reshape(1, 6000)
     pos, _, _ = ops.doc_ranges(big.to(DEV), 4095)
     assert int(pos.max()) == 4095   # clamped to the RoPE table
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_lmhead_ce_one_call_entries_equal_the_launch_sequence(ops, dtype):
+    """ssi_lmhead_ce_fwd / ssi_lmhead_ce_bwd (SURVEY.md §8b's export list) == head GEMM -> ssi_ce_fwd -> ssi_ce_reduce and the two
+    gradient GEMMs, bit for bit; and the loss against fp32 torch on the CPU."""
+    rows, dim, vocab, vpad = 256, 256, 700, 768
+    hn = rnd(rows, dim, dtype=dtype, seed=140)
+    table = rnd(vpad, dim, dtype=dtype, seed=141, scale=0.2)
+    table[vocab:] = 0
+    labels = torch.randint(0, vocab, (rows,), generator=torch.Generator().manual_seed(142))
+    labels[::9] = -100
+    h, e, lab = hn.to(DEV), table.to(DEV), labels.to(DEV)
+    # the sequence
+    logits = torch.empty(rows, vpad, dtype=dtype, device=DEV)
+    ops.gemm(ops.GEMM_NT, h, e, logits)
+    row_loss = torch.empty(rows, dtype=torch.float32, device=DEV)
+    ops.ce_fwd(logits, lab, vocab, -100, row_loss, None, True)
+    stats = torch.empty(4, dtype=torch.float32, device=DEV)
+    ops.ce_reduce(row_loss, lab, vocab, -100, stats)
+    alpha = torch.tensor([0.37], dtype=torch.float32, device=DEV)
+    d_h = torch.empty_like(h)
+    d_e = rnd(vpad, dim, dtype=dtype, seed=143).to(DEV)
+    d_e0 = d_e.clone()
+    ops.gemm(ops.GEMM_NN, logits, e, d_h, alpha_dev=alpha)
+    ops.gemm(ops.GEMM_TN, logits, h, d_e, alpha_dev=alpha, accumulate=True)
+    # one call each
+    ws = torch.full((rows, vpad), float("nan"), dtype=dtype, device=DEV)
+    rl2 = torch.empty_like(row_loss)
+    st2 = torch.empty_like(stats)
+    ops.lmhead_ce_fwd(h, e, lab, vocab, -100, ws, rl2, st2, True)
+    assert torch.equal(ws, logits) and torch.equal(rl2, row_loss) and torch.equal(st2, stats)
+    d_h2 = torch.full_like(h, float("nan"))
+    d_e2 = d_e0.clone()
+    ops.lmhead_ce_bwd(ws, h, e, alpha, d_h2, d_e2, True)
+    assert torch.equal(d_h2, d_h) and torch.equal(d_e2, d_e)
+    ref = F.cross_entropy((hn.float() @ table.float().t())[:, :vocab].to(dtype).float(), labels, ignore_index=-100, reduction="sum")
+    n_valid = int((labels != -100).sum())
+    assert st2.cpu()[2].item() == n_valid and st2.cpu()[3].item() == 0
+    assert st2.cpu()[1].item() == pytest.approx(float(ref), rel=1e-5 if dtype == torch.float32 else 2e-3)
