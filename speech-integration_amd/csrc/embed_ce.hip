@@ -348,9 +348,9 @@ __global__ __launch_bounds__(1024, 4) void ce_row_bf16_kernel(bf16_t* __restrict
                 bf16x8 ob;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)g[e];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), rs, voff, c * CHUNK * 2, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), rs, voff, c * CHUNK * 2, 2 /* nt: streamed once */);
             }
-            x[c] = __builtin_amdgcn_raw_buffer_load_b128(rn, voff, c * CHUNK * 2, 0);
+            x[c] = __builtin_amdgcn_raw_buffer_load_b128(rn, voff, c * CHUNK * 2, 2 /* nt */);
             __builtin_amdgcn_sched_barrier(0);  // one chunk at a time: a hoisted next-row load would need a register of its own
         }
     }
