@@ -470,28 +470,41 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
     const int qb_first = kgrp * 4;                       // first 32-query tile that sees any key of the group
     const int per_head = (q_end + 31) / 32 - qb_first;   // tiles per query head
     const int n_steps = per_head * rep;
-    // step -> (head of the group, query tile); each wave moves one 1-KiB piece of Q and one of dO per step
+    // step -> (head of the group, query tile); each wave moves one 1-KiB piece of Q and one of dO per step.  Steps are issued in
+    // order, so (head, tile) and the three source addresses advance incrementally: the per-step `step / per_head`, `step % per_head` and
+    // 64-bit address arithmetic cost 67 scalar instructions per step and wave before (SQ_INSTS_SALU), a fifth of the step's issue
+    int iss_qt = 0;                                  // query tile of the next request inside its head
+    const int irow = wave * 8 + (lane >> 3), ichunk = (lane & 7) ^ swz<SWZ_ROW>(wave * 8 + (lane >> 3));
+    const bf16_t* iss_q = qkv + (row0 + qb_first * 32 + irow) * ld + (int64_t)kvh * rep * HD + ichunk * 8;
+    const bf16_t* iss_do = dout + (row0 + qb_first * 32 + irow) * ldo + (int64_t)kvh * rep * HD + ichunk * 8;
+    const float* iss_rc = (lane < 32 ? lse : delta) + ((int64_t)b * H + kvh * rep) * S + qb_first * 32 + (lane & 31);
     auto issue = [&](int step) {
-        const int head = kvh * rep + step / per_head, q0 = (qb_first + step % per_head) * 32;
-        const int row = wave * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ swz<SWZ_ROW>(row);
         char* buf = smem + (step % RING) * SB;
-        __builtin_amdgcn_global_load_lds(
-            (__attribute__((address_space(1))) const void*)(qkv + (row0 + q0 + row) * ld + (int64_t)head * HD + chunk * 8),
-            (__attribute__((address_space(3))) void*)(buf + wave * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(
-            (__attribute__((address_space(1))) const void*)(dout + (row0 + q0 + row) * ldo + (int64_t)head * HD + chunk * 8),
-            (__attribute__((address_space(3))) void*)(buf + 4096 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)iss_q,
+                                         (__attribute__((address_space(3))) void*)(buf + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)iss_do,
+                                         (__attribute__((address_space(3))) void*)(buf + 4096 + wave * 1024), 16, 0, 0);
         // row constants of the tile: lanes 0-31 fetch lse[q0 + l], lanes 32-63 delta[q0 + l - 32] (every wave issues the same
         // 256-B request so that all waves count 3 requests per step)
-        const float* rc = (lane < 32 ? lse : delta) + ((int64_t)b * H + head) * S + q0 + (lane & 31);
-        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)rc,
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)iss_rc,
                                          (__attribute__((address_space(3))) void*)(buf + 8192), 4, 0, 0);
+        if (++iss_qt == per_head) {  // next head of the group: back to the first query tile, one head further
+            iss_qt = 0;
+            iss_q += (int64_t)HD - (int64_t)(per_head - 1) * 32 * ld;
+            iss_do += (int64_t)HD - (int64_t)(per_head - 1) * 32 * ldo;
+            iss_rc += (int64_t)S - (int64_t)(per_head - 1) * 32;
+        } else {
+            iss_q += 32 * ld;
+            iss_do += 32 * ldo;
+            iss_rc += 32;
+        }
     };
+    int cur_qt = 0;  // query tile of the step being computed (steps run in order too)
     // one step on ring buffer BUF (compile-time, so every LDS address is a hoisted per-lane base + an immediate)
     auto do_step = [&](int step, auto buf_c) {
         constexpr int BUF = decltype(buf_c)::value;
-        const int q0 = (qb_first + step % per_head) * 32;
+        const int q0 = (qb_first + cur_qt) * 32;
+        if (++cur_qt == per_head) cur_qt = 0;
         const char* qt = smem + BUF * SB;
         const char* dt = qt + 4096;
         const float* rcs = reinterpret_cast<const float*>(qt + 8192);
