@@ -63,6 +63,7 @@ __device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt
 
 constexpr int HD = 64;
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr float RESCALE_TAU = 5.545177444479562f;  // 8 ln 2
 
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -127,23 +128,57 @@ template <int ROWS, int NTHR> struct TileStage {
     }
 };
 
-// K and V tile (64 keys x 64 d each, 8 KiB + 8 KiB) of step t into a ring slot by LDS-DMA: each of the 4 waves moves two
-// 1-KiB pieces (8 rows x 128 B) of K and two of V = 4 requests per wave per tile.  The bank swizzle of each image is
-// applied on the per-lane SOURCE address (the LDS image of an LDS-DMA instruction is lane-linear).
-template <int SWZ_K, int SWZ_V>
-__device__ __forceinline__ void dma_kv_tile(const bf16_t* kbase, const bf16_t* vbase, int64_t ld, int t, char* slot, int wave,
-                                            int lane) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int piece = p * 4 + wave;  // 8 pieces of 8 rows
-        const int row = piece * 8 + (lane >> 3);
-        const int64_t goff = ((int64_t)t * 64 + row) * ld;
-        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(kbase + goff + ((lane & 7) ^ swz<SWZ_K>(row)) * 8),
-                                         (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(vbase + goff + ((lane & 7) ^ swz<SWZ_V>(row)) * 8),
-                                         (__attribute__((address_space(3))) void*)(slot + 8192 + piece * 1024), 16, 0, 0);
-    }
+// LDS-DMA requests are written as inline asm, not as __builtin_amdgcn_global_load_lds: the compiler knows that the builtin writes
+// LDS and puts `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove disjoint (every ds_read_b64_tr_b16 here), which
+// waits for the prefetches of the LATER tiles as well and turns a ring of N tiles into a ring of one.  With the asm form the only
+// waits are the counted ones written out next to the ring barriers.  A request = one wave-instruction: lane l's 16 (or 4) bytes at
+// rsrc base + voff(l) + soff go to LDS byte M0 + 16 l (4 l); the bank swizzle of a tile image is therefore applied on the per-lane
+// SOURCE offset.  The buffer form keeps the per-lane part of the address a constant 32-bit VGPR and the moving part a scalar.
+typedef __attribute__((address_space(3))) char lds_c;
+constexpr unsigned BUF_RSRC_WORD3 = 0x00020000u;  // raw buffer, 32-bit data format
+__device__ __forceinline__ u32x4 buffer_rsrc(const void* base) {  // stride 0, 2 GiB window
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r[2] = 0x7fffffffu;
+    r[3] = BUF_RSRC_WORD3;
+    return r;
 }
+__device__ __forceinline__ void dma16(unsigned lds_dst, unsigned voff, u32x4 rs, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma4(unsigned lds_dst, unsigned voff, u32x4 rs, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
+// K and V tiles (64 keys x 64 d each, 8 KiB + 8 KiB) of one (batch, kv head) into ring slots: each of the 4 waves moves two 1-KiB
+// pieces (8 rows x 128 B) of K and two of V = 4 requests per wave per tile.
+template <int SWZ_K, int SWZ_V> struct KvTileDma {
+    u32x4 rs;             // base = K rows of the batch, column block of the kv head
+    unsigned vk[2], vv[2];  // per-lane source byte offsets of the two K and the two V pieces inside a tile
+    unsigned lds_piece;   // LDS byte address of this wave's first piece in slot 0
+    unsigned tile_bytes;  // source bytes from one tile to the next
+    __device__ __forceinline__ void init(const bf16_t* kbase, int64_t ld, int kv_cols, const char* smem, int wave, int lane) {
+        rs = buffer_rsrc(kbase);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int row = (p * 4 + wave) * 8 + (lane >> 3);
+            vk[p] = (unsigned)((row * ld + ((lane & 7) ^ swz<SWZ_K>(row)) * 8) * 2);
+            vv[p] = (unsigned)((row * ld + kv_cols + ((lane & 7) ^ swz<SWZ_V>(row)) * 8) * 2);
+        }
+        lds_piece = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)smem + (unsigned)wave * 1024u);
+        tile_bytes = (unsigned)(64 * ld * 2);
+    }
+    __device__ __forceinline__ void tile(int t, unsigned slot_bytes) const {
+        const unsigned soff = (unsigned)t * tile_bytes;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            dma16(lds_piece + slot_bytes + p * 4096, vk[p], rs, soff);
+            dma16(lds_piece + slot_bytes + 8192 + p * 4096, vv[p], rs, soff);
+        }
+    }
+};
 
 // =====================================================================================================================
 // forward
@@ -169,7 +204,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const int h = lane >> 5;
     const int64_t row0 = (int64_t)b * S;
     const bf16_t* kbase = qkv + row0 * ld + (int64_t)H * HD + (int64_t)kvh * HD;
-    const bf16_t* vbase = kbase + (int64_t)KV * HD;
     // packed rows: a query sees keys doc_start <= key <= query.  doc_start is non-decreasing along a row, so the first key
     // tile any row of the workgroup / wave needs, and whether a tile needs the document mask, follow from the end rows.
     const int qg_ = q0 + (lane & 31);
@@ -190,12 +224,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    float m = -INFINITY, lsum = 0.f;  // running max (scaled-score units) and this half-wave's partial row sum
+    float m = -INFINITY, lsum = 0.f;  // reference max (scaled-score units) and this half-wave's partial row sum
+    float mb = 0.f;                   // m in exp2 units (0 while the row has seen no key)
     const int qg = q0 + (lane & 31);
 
     // ring of 3 tile slots filled by LDS-DMA two tiles ahead (4 requests per wave per tile)
-    dma_kv_tile<SWZ_ROW, SWZ_TR>(kbase, vbase, ld, t_first, smem, wave, lane);
-    if (t_first + 1 < nt) dma_kv_tile<SWZ_ROW, SWZ_TR>(kbase, vbase, ld, t_first + 1, smem + 16384, wave, lane);
+    KvTileDma<SWZ_ROW, SWZ_TR> kvdma;
+    kvdma.init(kbase, ld, KV * HD, smem, wave, lane);
+    kvdma.tile(t_first, 0);
+    if (t_first + 1 < nt) kvdma.tile(t_first + 1, 16384);
     auto tile_step = [&](int t, auto buf_c) {
         constexpr int BUF = decltype(buf_c)::value;  // compile-time ring slot: LDS addresses = hoisted lane base + immediate
         const char* kt = smem + BUF * 16384;
@@ -203,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // own pieces of tile t landed (tile t+1 may fly)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ring_barrier();  // everybody's pieces landed; the slot of tile t-1 is free again
-        if (t + 2 < nt) dma_kv_tile<SWZ_ROW, SWZ_TR>(kbase, vbase, ld, t + 2, smem + ((BUF + 2) % 3) * 16384, wave, lane);
+        if (t + 2 < nt) kvdma.tile(t + 2, ((BUF + 2) % 3) * 16384);
         const int k0 = t * 64;
         if (k0 <= q0 + 31 && k0 + 63 >= ds_lo) {  // wave-uniform: this tile intersects the visible range of the wave's rows
             f32x16 sacc[2];
@@ -230,11 +267,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m, mx);
-            // a row whose document starts after this tile has seen no key yet (m = mn = -inf): keep its state finite
-            const float mref = mn == -INFINITY ? 0.f : mn;
-            const float alpha = __builtin_amdgcn_exp2f((m - mref) * LOG2E);
-            const float mb = mref * LOG2E;
+            // Deferred rescale: the reference maximum m of a row moves only when the tile's maximum exceeds it by more than
+            // RESCALE_TAU, and then for the whole wave at once (wave-uniform branch), so most tiles skip the 32 multiplies of O^T and the
+            // extra exponential.  With a stale m the probabilities of a tile are at most e^TAU = 256 instead of 1: same relative precision in
+            // bf16, sums and O^T in fp32, and out = O / l, lse = m + log l do not depend on which m was used.
+            if (__builtin_amdgcn_ballot_w64(mx > m + RESCALE_TAU) != 0) {
+                const float mn = fmaxf(m, mx);
+                // a row whose document starts after this tile has seen no key yet (m = mn = -inf): keep its state finite
+                const float mref = mn == -INFINITY ? 0.f : mn;
+                const float alpha = __builtin_amdgcn_exp2f((m - mref) * LOG2E);
+                mb = mref * LOG2E;
+                lsum *= alpha;
+                m = mn;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+            }
             float rs = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -244,12 +293,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                     sacc[kb][r] = p;
                     rs += p;
                 }
-            lsum = lsum * alpha + rs;
-            m = mn;
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+            lsum += rs;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bf16x8 pf = acc_frag(sacc[s >> 1], s & 1);
@@ -303,7 +347,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     const int h = lane >> 5;
     const int64_t row0 = (int64_t)b * S;
     const bf16_t* kbase = qkv + row0 * ld + (int64_t)H * HD + (int64_t)kvh * HD;
-    const bf16_t* vbase = kbase + (int64_t)KV * HD;
     const int qg = q0 + (lane & 31);
     // packed rows: see attn_fwd_kernel
     const int ds = doc_start ? doc_start[row0 + qg] : 0;
@@ -342,8 +385,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
-    dma_kv_tile<SWZ_ROW, SWZ_ROW>(kbase, vbase, ld, t_first, smem, wave, lane);
-    if (t_first + 1 < nt) dma_kv_tile<SWZ_ROW, SWZ_ROW>(kbase, vbase, ld, t_first + 1, smem + 16384, wave, lane);
+    KvTileDma<SWZ_ROW, SWZ_ROW> kvdma;
+    kvdma.init(kbase, ld, KV * HD, smem, wave, lane);
+    kvdma.tile(t_first, 0);
+    if (t_first + 1 < nt) kvdma.tile(t_first + 1, 16384);
     auto tile_step = [&](int t, auto buf_c) {
         constexpr int BUF = decltype(buf_c)::value;
         const char* kt = smem + BUF * 16384;
@@ -351,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // own pieces of tile t landed (tile t+1 may fly)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ring_barrier();  // everybody's pieces landed; the slot of tile t-1 is free again
-        if (t + 2 < nt) dma_kv_tile<SWZ_ROW, SWZ_ROW>(kbase, vbase, ld, t + 2, smem + ((BUF + 2) % 3) * 16384, wave, lane);
+        if (t + 2 < nt) kvdma.tile(t + 2, ((BUF + 2) % 3) * 16384);
         const int k0 = t * 64;
         if (k0 <= q0 + 31 && k0 + 63 >= ds_lo) {
             f32x16 sacc[2], pacc[2];
@@ -475,27 +520,28 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
     // 64-bit address arithmetic cost 67 scalar instructions per step and wave before (SQ_INSTS_SALU), a fifth of the step's issue
     int iss_qt = 0;                                  // query tile of the next request inside its head
     const int irow = wave * 8 + (lane >> 3), ichunk = (lane & 7) ^ swz<SWZ_ROW>(wave * 8 + (lane >> 3));
-    const bf16_t* iss_q = qkv + (row0 + qb_first * 32 + irow) * ld + (int64_t)kvh * rep * HD + ichunk * 8;
-    const bf16_t* iss_do = dout + (row0 + qb_first * 32 + irow) * ldo + (int64_t)kvh * rep * HD + ichunk * 8;
+    const u32x4 rs_q = buffer_rsrc(qkv + row0 * ld + (int64_t)kvh * rep * HD);    // Q columns of the group's first head, this batch
+    const u32x4 rs_do = buffer_rsrc(dout + row0 * ldo + (int64_t)kvh * rep * HD);
+    const unsigned voff_q = (unsigned)((irow * ld + ichunk * 8) * 2), voff_do = (unsigned)((irow * ldo + ichunk * 8) * 2);
+    unsigned soff_q = (unsigned)(qb_first * 32 * ld * 2), soff_do = (unsigned)(qb_first * 32 * ldo * 2);  // scalar, advanced per request
     const float* iss_rc = (lane < 32 ? lse : delta) + ((int64_t)b * H + kvh * rep) * S + qb_first * 32 + (lane & 31);
+    const unsigned lds_piece = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)smem + (unsigned)wave * 1024u);
+    const unsigned lds_rc = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)smem + 8192u);
     auto issue = [&](int step) {
-        char* buf = smem + (step % RING) * SB;
-        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)iss_q,
-                                         (__attribute__((address_space(3))) void*)(buf + wave * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)iss_do,
-                                         (__attribute__((address_space(3))) void*)(buf + 4096 + wave * 1024), 16, 0, 0);
+        const unsigned buf = (unsigned)(step % RING) * SB;
+        dma16(lds_piece + buf, voff_q, rs_q, soff_q);
+        dma16(lds_piece + buf + 4096, voff_do, rs_do, soff_do);
         // row constants of the tile: lanes 0-31 fetch lse[q0 + l], lanes 32-63 delta[q0 + l - 32] (every wave issues the same
-        // 256-B request so that all waves count 3 requests per step)
-        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)iss_rc,
-                                         (__attribute__((address_space(3))) void*)(buf + 8192), 4, 0, 0);
+        // 256-B request so that all waves count 3 requests per step); two arrays, hence per-lane 64-bit addresses
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_rc + buf), "v"(iss_rc) : "memory");
         if (++iss_qt == per_head) {  // next head of the group: back to the first query tile, one head further
             iss_qt = 0;
-            iss_q += (int64_t)HD - (int64_t)(per_head - 1) * 32 * ld;
-            iss_do += (int64_t)HD - (int64_t)(per_head - 1) * 32 * ldo;
+            soff_q += (unsigned)(HD * 2) - (unsigned)((per_head - 1) * 32 * ld * 2);
+            soff_do += (unsigned)(HD * 2) - (unsigned)((per_head - 1) * 32 * ldo * 2);
             iss_rc += (int64_t)S - (int64_t)(per_head - 1) * 32;
         } else {
-            iss_q += 32 * ld;
-            iss_do += 32 * ldo;
+            soff_q += (unsigned)(32 * ld * 2);
+            soff_do += (unsigned)(32 * ldo * 2);
             iss_rc += 32;
         }
     };
