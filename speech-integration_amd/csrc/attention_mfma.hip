@@ -67,9 +67,17 @@ constexpr float RESCALE_TAU = 5.545177444479562f;  // 8 ln 2
 
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-enum { SWZ_ROW = 0, SWZ_TR = 1 };
+// 16-B-chunk XOR swizzles of a [rows][64] bf16 tile (two 128-B rows per 256-B bank row):
+//   SWZ_ROW  f = (row >> 1) & 7: the 8 same-parity rows of a ds_read_b128 lane group land on 8 different chunks   (row reads only)
+//   SWZ_TR   f = 4 * bit 1 of row: rows r and r + 2 of a transposed 4-row block land on opposite halves of the row (transposed reads only)
+//   SWZ_DUAL both at once: the three bits of (row >> 1) rotated so that bit 1 of the row becomes bit 2 of f — still 8 different values on
+//            the row-read groups, and r / r + 2 differ in bit 2.  With SWZ_ROW a tile that is ALSO read transposed (K in dQ, Q and dO in
+//            dK/dV) cost every ds_read_b64_tr_b16 a 2-way conflict (SQ_LDS_BANK_CONFLICT = one extra cycle per LDS instruction).
+enum { SWZ_ROW = 0, SWZ_TR = 1, SWZ_DUAL = 2 };
 template <int SWZ> __device__ __forceinline__ int swz(int row) {
-    return SWZ == SWZ_ROW ? ((row >> 1) & 7) : (((row >> 1) & 1) << 2);
+    if (SWZ == SWZ_ROW) return (row >> 1) & 7;
+    if (SWZ == SWZ_TR) return ((row >> 1) & 1) << 2;
+    return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
 }
 
 // 32 rows x 16 k fragment of a [rows][64] tile: lane l holds row = row_base + (l & 31), k = 16 ks + 8 (l >> 5) + j
@@ -243,15 +251,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         if (t + 2 < nt) kvdma.tile(t + 2, ((BUF + 2) % 3) * 16384);
         const int k0 = t * 64;
         if (k0 <= q0 + 31 && k0 + 63 >= ds_lo) {  // wave-uniform: this tile intersects the visible range of the wave's rows
+            // All 8 K fragments are requested before the first product and all 16 V fragments right behind the S^T products (they land
+            // under the softmax).  Left to itself the compiler reads each fragment into the same registers right in front of its MFMA
+            // (read, lgkmcnt(0), MFMA, read, ...), which exposes the LDS latency once per MFMA.
+            bf16x8 kfr[2][4];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kfr[kb][ks] = frag_row<SWZ_ROW>(kt, kb * 32, ks, lane);
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 sacc[2];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(kt, kb * 32, ks, lane), qf[ks], sacc[kb], 0, 0, 0);
-            }
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][ks], qf[ks], sacc[kb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 vfr[4][2];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) vfr[s][db] = frag_tr<SWZ_TR>(vt, s * 16, db * 32, lane);
+            __builtin_amdgcn_sched_barrier(0);
             if (k0 + 63 > q0 || k0 < ds_hi) {  // edge tile: mask keys beyond the query or before its document
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -299,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                 const bf16x8 pf = acc_frag(sacc[s >> 1], s & 1);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_TR>(vt, s * 16, db * 32, lane), pf, oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[s][db], pf, oacc[db], 0, 0, 0);
             }
         }
     };
@@ -385,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
-    KvTileDma<SWZ_ROW, SWZ_ROW> kvdma;
+    KvTileDma<SWZ_DUAL, SWZ_ROW> kvdma;
     kvdma.init(kbase, ld, KV * HD, smem, wave, lane);
     kvdma.tile(t_first, 0);
     if (t_first + 1 < nt) kvdma.tile(t_first + 1, 16384);
@@ -399,17 +423,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         if (t + 2 < nt) kvdma.tile(t + 2, ((BUF + 2) % 3) * 16384);
         const int k0 = t * 64;
         if (k0 <= q0 + 31 && k0 + 63 >= ds_lo) {
+            // fragment reads ahead of the products that use them (see attn_fwd_kernel)
+            bf16x8 kfr[2][4], vfr[2][4];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    kfr[kb][ks] = frag_row<SWZ_DUAL>(kt, kb * 32, ks, lane);
+                    vfr[kb][ks] = frag_row<SWZ_ROW>(vt, kb * 32, ks, lane);
+                }
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 sacc[2], pacc[2];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { sacc[kb][r] = -lq; pacc[kb][r] = -dl; }  // S'^T = K Q^T - lse, dP'^T = V dO^T - delta
 #pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(kt, kb * 32, ks, lane), qf[ks], sacc[kb], 0, 0, 0);
-                    pacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(vt, kb * 32, ks, lane), dof[ks], pacc[kb], 0, 0, 0);
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][ks], qf[ks], sacc[kb], 0, 0, 0);
+                    pacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb][ks], dof[ks], pacc[kb], 0, 0, 0);
                 }
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 ktr[4][2];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) ktr[s][db] = frag_tr<SWZ_DUAL>(kt, s * 16, db * 32, lane);
+            __builtin_amdgcn_sched_barrier(0);
             if (k0 + 63 > q0 || k0 < ds_hi) {  // edge tile: keys beyond the query or before its document contribute nothing
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -431,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                 const bf16x8 dsf = acc_frag(sacc[s >> 1], s & 1);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(kt, s * 16, db * 32, lane), dsf, dq[db], 0, 0, 0);
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[s][db], dsf, dq[db], 0, 0, 0);
             }
         }
     };
@@ -519,7 +561,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
     // order, so (head, tile) and the three source addresses advance incrementally: the per-step `step / per_head`, `step % per_head` and
     // 64-bit address arithmetic cost 67 scalar instructions per step and wave before (SQ_INSTS_SALU), a fifth of the step's issue
     int iss_qt = 0;                                  // query tile of the next request inside its head
-    const int irow = wave * 8 + (lane >> 3), ichunk = (lane & 7) ^ swz<SWZ_ROW>(wave * 8 + (lane >> 3));
+    const int irow = wave * 8 + (lane >> 3), ichunk = (lane & 7) ^ swz<SWZ_DUAL>(wave * 8 + (lane >> 3));
     const u32x4 rs_q = buffer_rsrc(qkv + row0 * ld + (int64_t)kvh * rep * HD);    // Q columns of the group's first head, this batch
     const u32x4 rs_do = buffer_rsrc(dout + row0 * ldo + (int64_t)kvh * rep * HD);
     const unsigned voff_q = (unsigned)((irow * ld + ichunk * 8) * 2), voff_do = (unsigned)((irow * ldo + ichunk * 8) * 2);
@@ -571,11 +613,29 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
 #pragma unroll
             for (int e = 0; e < 4; ++e) { sacc[4 * g + e] = l4[e]; pacc[4 * g + e] = d4[e]; }
         }
+        // fragment reads ahead of the products that use them (see attn_fwd_kernel)
+        bf16x8 qfr[4], dfr[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(qt, 0, ks, lane), kf[ks], sacc, 0, 0, 0);
-            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<SWZ_ROW>(dt, 0, ks, lane), vf[ks], pacc, 0, 0, 0);
+            qfr[ks] = frag_row<SWZ_DUAL>(qt, 0, ks, lane);
+            dfr[ks] = frag_row<SWZ_DUAL>(dt, 0, ks, lane);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ks], kf[ks], sacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[ks], vf[ks], pacc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 dtr[2][2], qtr[2][2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                dtr[s2][db] = frag_tr<SWZ_DUAL>(dt, s2 * 16, db * 32, lane);
+                qtr[s2][db] = frag_tr<SWZ_DUAL>(qt, s2 * 16, db * 32, lane);
+            }
+        __builtin_amdgcn_sched_barrier(0);
         if (q0 < key0 + 32 || q0 + 31 >= de_lo) {  // edge tile: keys beyond the query or of an earlier document contribute nothing
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -598,8 +658,8 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
             const bf16x8 pf = acc_frag(sacc, s2), dsf = acc_frag(pacc, s2);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(dt, s2 * 16, db * 32, lane), pf, dv[db], 0, 0, 0);
-                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<SWZ_ROW>(qt, s2 * 16, db * 32, lane), dsf, dk[db], 0, 0, 0);
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dtr[s2][db], pf, dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtr[s2][db], dsf, dk[db], 0, 0, 0);
             }
         }
     };
