@@ -102,9 +102,24 @@ class GemmTimer:
             prev = 1 if kw.get("accumulate") else (2 if kw.get("residual") is not None else 0)
             timer.records.append(((layout, prev), 2.0 * M * N * K, s, e))
 
+        inner_b = ops.gemm_batched
+
+        def timed_gemm_batched(layout, a, b, c, **kw):  # the deferred attention-projection weight gradients (one launch per group of layers)
+            if not timer.enabled:
+                return inner_b(layout, a, b, c, **kw)
+            n, M, N = c.shape
+            K = a.shape[2] if layout in (ops.GEMM_NT, ops.GEMM_NN) else a.shape[1]
+            st = torch.cuda.current_stream().cuda_stream
+            s = timer.ev.record(st)
+            inner_b(layout, a, b, c, **kw)
+            e = timer.ev.record(st)
+            timer.records.append(((layout, 1 if kw.get("accumulate") else 0, "batched"), 2.0 * n * M * N * K, s, e))
+
         ops.gemm = timed_gemm
+        ops.gemm_batched = timed_gemm_batched
         import ssi.model as m
         m.ops.gemm = timed_gemm
+        m.ops.gemm_batched = timed_gemm_batched
 
     def summary(self):
         tot_ms, tot_fl, per = 0.0, 0.0, {}
@@ -376,10 +391,11 @@ def main() -> int:
             out["gflop_per_token"] = f_tok / 1e9
         if timer.records:
             _, _, per = timer.summary()
-            # one kernel symbol per (operand layout, epilogue) class: gemm_nt4dma_kernel<A_COL, B_COL, EPI_PLAIN, PREV, SPLITK=false> (the LDS-DMA loop); the roofline
-            # object is the class with the largest share of the step
+            # one kernel symbol per (operand layout, epilogue) class: gemm_nt4dma_kernel<A_COL, B_COL, EPI_PLAIN, PREV, SPLITK=false, BATCHED> (the LDS-DMA
+            # loop); the roofline object is the class with the largest share of the step
             lay = {0: "false,false", 1: "false,true", 2: "true,true"}
-            sym = {(l, pv): f"gemm_nt4dma_kernel<{lay[l]},0,{pv},false>" for l in lay for pv in (0, 1, 2)}
+            sym = {(l, pv): f"gemm_nt4dma_kernel<{lay[l]},0,{pv},false,false>" for l in lay for pv in (0, 1, 2)}
+            sym.update({(l, pv, "batched"): f"gemm_nt4dma_kernel<{lay[l]},0,{pv},false,true>" for l in lay for pv in (0, 1)})
             dom = max(per, key=lambda k: per[k][1])
             n, ms, fl = per[dom]
             out["roofline"] = {

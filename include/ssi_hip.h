@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define SSI_ABI_VERSION 3 /* 2: + ssi_attn_varlen_fwd/bwd(_rope), ssi_set_gemm_tile_order, NN form of ssi_gemm_swiglu_bwd
+#define SSI_ABI_VERSION 4 /* 4: + ssi_gemm_batched
+                           * 2: + ssi_attn_varlen_fwd/bwd(_rope), ssi_set_gemm_tile_order, NN form of ssi_gemm_swiglu_bwd
                            * 3: ssi_ce_reduce takes `vocab` and reports out-of-range labels in out[3]; + ssi_doc_ranges; ssi_rmsnorm_bwd takes accumulate_dscale; + ssi_lmhead_ce_fwd/bwd */
 
 enum { SSI_F32 = 0, SSI_BF16 = 1 };
@@ -145,6 +146,15 @@ int64_t ssi_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int splits);
 int ssi_gemm_splitk(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
                     void* C, int64_t ldc, const void* R, float alpha, const float* alpha_dev, int accumulate, int dtype,
                     int splits, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* `batch` GEMMs of one shape in ONE launch: problem b works on A + b strideA, B + b strideB, C + b strideC (strides in elements, no
+ * residual).  For contractions whose output grid cannot fill the 256 CUs but which come in independent copies: the weight gradients
+ * of the square projections (F.linear's autograd for attn.output_proj: 64 output tiles, fused q/k/v_proj: 96) of several LAYERS,
+ * which the model defers until a group of layers has finished its backward — at full K, with no fp32 partials and no reduction pass.
+ * MFMA path: SSI_GEMM_TN, bf16, ssi_gemm's shape rules, K % 128 == 0; anything else runs as `batch` ssi_gemm calls (same results). */
+int ssi_gemm_batched(int layout, int batch, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, int64_t strideA, const void* B,
+                     int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC, float alpha, const float* alpha_dev,
+                     int accumulate, int dtype, void* stream);
 
 /* Fused SwiGLU GEMMs (torchtune FeedForward and its autograd): the elementwise stage rides in the GEMM epilogue on the MFMA
  * path (bf16, M % 256 == 0, I % 256 == 0, K % 64 == 0); otherwise the unfused kernels run.  Same rounding points either way.

@@ -125,6 +125,40 @@ extern "C" int ssi_gemm(int layout, int64_t M, int64_t N, int64_t K, const void*
     return SSI_OK;
 }
 
+// `batch` GEMMs of one shape in one launch: problem b works on A + b strideA, B + b strideB, C + b strideC (strides in elements).
+// For contractions whose output grid cannot fill 256 CUs but which come in several independent copies: the weight gradients of the
+// square projections (dW_o: 64 output tiles, dW_qkv: 96) of several LAYERS, deferred by the model until a group of layers has finished
+// its backward, fill the chip as one launch at full K instead of a split-K launch + reduction per layer.  Shapes the persistent MFMA kernel
+// does not take run as `batch` ssi_gemm calls.
+bool ssi_gemm_mfma_bf16_batched(int layout, int batch, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, int64_t bsA, const void* B,
+                                int64_t ldb, int64_t bsB, void* C, int64_t ldc, int64_t bsC, float alpha, const float* alpha_dev, int accumulate,
+                                void* stream, int* rc);
+extern "C" int ssi_gemm_batched(int layout, int batch, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, int64_t strideA,
+                                const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC, float alpha,
+                                const float* alpha_dev, int accumulate, int dtype, void* stream) {
+    SSI_CHECK_ARG(batch >= 0 && strideA >= 0 && strideB >= 0 && strideC >= 0);
+    SSI_CHECK_ARG(dtype == SSI_BF16 || dtype == SSI_F32);
+    if (batch == 0) return SSI_OK;
+    SSI_CHECK_ARG(A && B && C);
+    const int64_t es = dtype == SSI_BF16 ? 2 : 4;
+    auto off = [&](const void* p, int64_t b, int64_t stride) { return (const void*)((const char*)p + b * stride * es); };
+    bool mfma_ok = dtype == SSI_BF16 && batch > 1 && g_impl != SSI_IMPL_GENERIC && g_impl != SSI_IMPL_MFMA_WG8;
+    for (int b = 0; b < batch && mfma_ok; ++b)
+        mfma_ok = ssi_gemm_mfma_supported(layout, M, N, K, off(A, b, strideA), lda, off(B, b, strideB), ldb, off(C, b, strideC), ldc, nullptr);
+    if (mfma_ok) {
+        SSI_CHECK_ARG(layout == SSI_GEMM_NT || layout == SSI_GEMM_NN || layout == SSI_GEMM_TN);
+        int rc = SSI_OK;
+        if (ssi_gemm_mfma_bf16_batched(layout, batch, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, alpha, alpha_dev, accumulate,
+                                       stream, &rc))
+            return rc;
+    }
+    for (int b = 0; b < batch; ++b)
+        if (int rc = ssi_gemm(layout, M, N, K, off(A, b, strideA), lda, off(B, b, strideB), ldb, (void*)off(C, b, strideC), ldc, nullptr, alpha,
+                              alpha_dev, accumulate, dtype, stream))
+            return rc;
+    return SSI_OK;
+}
+
 // Split-K form of ssi_gemm for contractions whose output grid cannot fill 256 CUs (weight gradients of the square
 // projections: K = tokens is long, M x N is small).  The K range is cut into `splits` slices computed by separate
 // workgroups into fp32 slabs ([splits, M, N] in `workspace`), then one pass sums the slabs and applies the epilogue.

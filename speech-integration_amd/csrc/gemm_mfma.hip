@@ -153,6 +153,10 @@ struct EpiArgs {
     const int32_t* pos = nullptr;   // [M] positions, or NULL: position = row % seq
     int64_t seq = 1;
     int64_t rot_cols = 0;
+    // batched form (EPI_PLAIN, no split-K): `batch` problems of one shape in one launch; tile t belongs to problem t / (tiles_m * tiles_n),
+    // whose operands start bsA / bsB / bsC elements after those of the problem before (C's stride also applies to R)
+    int batch = 1;
+    int64_t bsA = 0, bsB = 0, bsC = 0;
 };
 
 template <bool A_COL, bool B_COL, bool SPLITK, int EPI = EPI_PLAIN>
@@ -521,7 +525,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 //      (unit, wave, 16x16 tile, lane: every store is one contiguous KiB) and nt4_splitk_reduce_kernel finishes the tile
 // DMA (k-contiguous operands only): the operand stream goes HBM -> LDS by LDS-DMA (buffer_load ... lds, no staging registers, no
 //      ds_write) two K-steps ahead, and the registers hold a whole K-step of fragments instead (see the DMA main loop below)
-template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK, bool DMA>
+template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK, bool DMA, bool BATCHED = false>
 __device__ __forceinline__ void nt4_body(char* smem, int tiles_m, int tiles_n, int64_t K, const bf16_t* __restrict__ A,
                                          int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                          bf16_t* __restrict__ C, int64_t ldc, const bf16_t* __restrict__ R,
@@ -530,8 +534,16 @@ __device__ __forceinline__ void nt4_body(char* smem, int tiles_m, int tiles_n, i
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntiles_out = tiles_m * tiles_n;
+    const int per_prob = tiles_m * tiles_n;        // output tiles of one problem
+    const int ntiles_out = BATCHED ? per_prob * ea.batch : per_prob;  // output tiles of the launch (BATCHED: ssi_gemm_batched)
     const int ntiles = SPLITK ? ntiles_out * splits : ntiles_out;  // units of work
+    // unit -> (problem, tile coordinates inside it)
+    auto locate = [&](int t, int& tm, int& tn) {
+        int tt = SPLITK ? t % ntiles_out : t, pb = 0;
+        if constexpr (BATCHED) { pb = tt / per_prob; tt -= pb * per_prob; }
+        tile_from_t(tt, tiles_m, tiles_n, tm, tn);
+        return pb;
+    };
     const int G = (int)gridDim.x;
     const int nk_total = (int)(K / BK);  // even, >= 4 (per K-slice when SPLITK)
     // K-steps [k_lo, k_hi) of unit t (slice boundaries rounded to even step counts)
@@ -607,10 +619,12 @@ __device__ __forceinline__ void nt4_body(char* smem, int tiles_m, int tiles_n, i
     const int64_t kstepA_ = A_COL ? BK * lda : BK, kstepB_ = B_COL ? BK * ldb : BK;
     auto set_load_tile = [&](int t) {
         int tm, tn;
-        tile_from_t(SPLITK ? t % ntiles_out : t, tiles_m, tiles_n, tm, tn);
-        baseA = (A_COL ? A + (int64_t)tm * BM : A + (int64_t)tm * BM * lda) + k_lo(t) * kstepA_;
+        const int pb = locate(t, tm, tn);
+        const bf16_t* Ap = BATCHED ? A + pb * ea.bsA : A;
+        const bf16_t* Bp = BATCHED ? B + pb * ea.bsB : B;
+        baseA = (A_COL ? Ap + (int64_t)tm * BM : Ap + (int64_t)tm * BM * lda) + k_lo(t) * kstepA_;
         // SwiGLU forward: the 256 tile columns are [gate 0..63 | up 0..63 | gate 64..127 | up 64..127] of 128 W13 column pairs
-        baseB = (B_COL ? B + (int64_t)tn * BN : B + (int64_t)tn * (EPI == EPI_SWIGLU_FWD ? BN / 2 : BN) * ldb) + k_lo(t) * kstepB_;
+        baseB = (B_COL ? Bp + (int64_t)tn * BN : Bp + (int64_t)tn * (EPI == EPI_SWIGLU_FWD ? BN / 2 : BN) * ldb) + k_lo(t) * kstepB_;
         lnk = k_hi(t) - k_lo(t);
     };
     auto advance = [&]() {
@@ -876,7 +890,7 @@ __device__ __forceinline__ void nt4_body(char* smem, int tiles_m, int tiles_n, i
     const int g = lane >> 4;
     while (cur >= 0) {
         int tm, tn;
-        tile_from_t(SPLITK ? cur % ntiles_out : cur, tiles_m, tiles_n, tm, tn);
+        const int pb = locate(cur, tm, tn);
         const int nk = k_hi(cur) - k_lo(cur);
         using B0_ = std::integral_constant<int, 0>;
         using B1_ = std::integral_constant<int, 1>;
@@ -955,7 +969,7 @@ __device__ __forceinline__ void nt4_body(char* smem, int tiles_m, int tiles_n, i
         const int lane_row = lane & 7, lane_col = ((lane >> 3) & 1) * 32 + (g & 1) * 16 + (g >> 1) * 8;
         auto epilogue = [&](auto scale_c) {
         if constexpr (EPI == EPI_PLAIN) {
-            const int64_t tile_off = row0 * ldc + (int64_t)tn * BN + wn * NT4_WN;
+            const int64_t tile_off = (BATCHED ? pb * ea.bsC : 0) + row0 * ldc + (int64_t)tn * BN + wn * NT4_WN;
             const __amdgpu_buffer_rsrc_t rsC = make_rsrc(C + tile_off);
             const __amdgpu_buffer_rsrc_t rsP = make_rsrc(PREV == 2 ? R + tile_off : C + tile_off);
             const int voff = (int)((lane_row * ldc + lane_col) * 2);
@@ -1152,15 +1166,15 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4_kernel(int tiles_m, i
     nt4_body<A_COL, B_COL, EPI, PREV, SPLITK, false>(smem, tiles_m, tiles_n, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, ea, slot, splits, slabs);
 }
 
-// the LDS-DMA main loop (same tile walk, scheduler and epilogues)
-template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK = false>
+// the LDS-DMA main loop (same tile walk, scheduler and epilogues); BATCHED: several problems of one shape in one launch (EpiArgs::batch)
+template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK = false, bool BATCHED = false>
 __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4dma_kernel(int tiles_m, int tiles_n, int64_t K, const bf16_t* __restrict__ A,
                                                                      int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                                      bf16_t* __restrict__ C, int64_t ldc, const bf16_t* __restrict__ R,
                                                                      float alpha, const float* __restrict__ alpha_dev, EpiArgs ea, int slot,
                                                                      int splits, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    nt4_body<A_COL, B_COL, EPI, PREV, SPLITK, true>(smem, tiles_m, tiles_n, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, ea, slot, splits, slabs);
+    nt4_body<A_COL, B_COL, EPI, PREV, SPLITK, true, BATCHED>(smem, tiles_m, tiles_n, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, ea, slot, splits, slabs);
 }
 
 // Finishes split-K tiles: one wave per (output tile, wave of the GEMM workgroup, m-tile i, 64-column duo).  Sums the K-slices'
@@ -1224,13 +1238,14 @@ __global__ __launch_bounds__(256) void nt4_splitk_reduce_kernel(const float* __r
     finish(hi, base + 8 * ldc);
 }
 
-template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK = false, bool DMA = false>
+template <bool A_COL, bool B_COL, int EPI, int PREV, bool SPLITK = false, bool DMA = false, bool BATCHED = false>
 int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                const void* R, float alpha, const float* alpha_dev, hipStream_t st, EpiArgs ea = EpiArgs{nullptr, 0, nullptr, 0, 0},
                int splits = 1, float* slabs = nullptr) {
     void (*kern)(int, int, int64_t, const bf16_t*, int64_t, const bf16_t*, int64_t, bf16_t*, int64_t, const bf16_t*, float, const float*, EpiArgs, int, int,
                  float*);
-    if constexpr (DMA) kern = gemm_nt4dma_kernel<A_COL, B_COL, EPI, PREV, SPLITK>;
+    static_assert(!BATCHED || (DMA && !SPLITK && EPI == EPI_PLAIN), "batched form: LDS-DMA loop, plain epilogue, no split-K");
+    if constexpr (DMA) kern = gemm_nt4dma_kernel<A_COL, B_COL, EPI, PREV, SPLITK, BATCHED>;
     else kern = gemm_nt4_kernel<A_COL, B_COL, EPI, PREV, SPLITK>;
     // one-time set-up per instantiation as C++11 thread-safe statics: the forward thread and autograd's backward thread may both be the
     // first to launch a given form
@@ -1241,7 +1256,7 @@ int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, 
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         return cus;
     }();
-    const int ntiles = tiles_m * tiles_n * (SPLITK ? splits : 1);
+    const int ntiles = tiles_m * tiles_n * (SPLITK ? splits : 1) * (BATCHED ? ea.batch : 1);
     int grid = ntiles < num_cu ? ntiles : num_cu;
     const int slot = g_nt4_dynamic.load(std::memory_order_relaxed) ? (int)(nt4_next_slot() & 15) : -1;  // consecutive launches: different slots
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT4_THREADS), NT4_LDS_BYTES, st, tiles_m, tiles_n, K, (const bf16_t*)A, lda,
@@ -1313,6 +1328,22 @@ int ssi_gemm_mfma_bf16(int layout, int64_t M, int64_t N, int64_t K, const void* 
     }
 #undef GO
     return SSI_ERR_ARG;
+}
+
+// `batch` problems of one shape in one launch of the persistent kernel: the weight-gradient form (TN) on the LDS-DMA loop, no residual;
+// false = not taken, the caller loops over ssi_gemm
+bool ssi_gemm_mfma_bf16_batched(int layout, int batch, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, int64_t bsA, const void* B,
+                                int64_t ldb, int64_t bsB, void* C, int64_t ldc, int64_t bsC, float alpha, const float* alpha_dev, int accumulate,
+                                void* stream, int* rc) {
+    if (layout != SSI_GEMM_TN || !TN_DMA || !nt4_ok(K) || !nt4_ld_ok(lda, ldb) || (bsA | bsB | bsC) % 8 || (M / BM) * (N / BN) * batch > (1LL << 30))
+        return false;
+    const int tm = (int)(M / BM), tn = (int)(N / BN);
+    auto st = (hipStream_t)stream;
+    EpiArgs ea{nullptr, 0, nullptr, 0, 0};
+    ea.batch = batch; ea.bsA = bsA; ea.bsB = bsB; ea.bsC = bsC;
+    *rc = accumulate ? launch_nt4<true, true, EPI_PLAIN, 1, false, true, true>(tm, tn, K, A, lda, B, ldb, C, ldc, nullptr, alpha, alpha_dev, st, ea)
+                     : launch_nt4<true, true, EPI_PLAIN, 0, false, true, true>(tm, tn, K, A, lda, B, ldb, C, ldc, nullptr, alpha, alpha_dev, st, ea);
+    return true;
 }
 
 int ssi_gemm_mfma_bf16_splitk(int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,

@@ -20,7 +20,7 @@ SSI_F32, SSI_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_MFMA_WG8 = 0, 1, 2, 3
 TILES_STATIC, TILES_DYNAMIC = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> (restype, argtypes); mirrors include/ssi_hip.h line by line
 _P = c_void_p
@@ -52,6 +52,8 @@ PROTOTYPES = {
     "ssi_gemm_splitk_workspace_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "ssi_gemm_splitk": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_float, _P,
                                 c_int, c_int, c_int, _P, c_int64, _P]),
+    "ssi_gemm_batched": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
+                                 c_float, _P, c_int, c_int, _P]),
     "ssi_gemm_swiglu_fwd": (c_int, [c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int, _P]),
     "ssi_gemm_swiglu_bwd": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int,
                                     _P]),

@@ -136,10 +136,15 @@ class HipLlamaDecoder(nn.Module):
             self._slices[name] = (off, shape)
             off += _align(n, 8)
 
+        # [E_pad | attention weights of every layer: L0.wqkv, L0.wo, L1.wqkv, ... | L0: w13, w2, sa_norm, mlp_norm | L1: ... | norm].
+        # The attention projections sit together, one layer after the other at a fixed stride: their weight gradients (64 and 96 output
+        # tiles, too few for 256 CUs) are computed for a GROUP of layers in one batched launch (_backward_hidden), which then finishes a
+        # contiguous range of the gradient buffer = one data-parallel bucket per group.
         take("emb", (self.vocab_pad, D))
         for l in range(num_layers):
             take(f"L{l}.wqkv", (self.qkv_dim, D))
             take(f"L{l}.wo", (D, Q))
+        for l in range(num_layers):
             take(f"L{l}.w13", (2 * I, D))
             take(f"L{l}.w2", (D, I))
             take(f"L{l}.sa_norm", (D,))
@@ -154,15 +159,23 @@ class HipLlamaDecoder(nn.Module):
         self._wt_key: Optional[tuple] = None
         self._hip_epoch = 0  # bumped by kernels that modify the weights in place (fused AdamW)
         self._grad_views: dict[str, Tensor] = {}
-        # DP buckets in the order backward finishes them: final norm, layers L-1..0, embedding (tied: finished last)
+        # Layers whose attention-projection weight gradients share one batched launch (0 / 1 = every layer on its own, split-K).  8 at the
+        # 1B shape: 8 x 64 and 8 x 96 output tiles = 2 and 3 full rounds of the 256 CUs.
+        self.wgrad_group = max(1, min(int(os.environ.get("SSI_WGRAD_GROUP", "8")), max(num_layers, 1)))
+        # DP buckets in the order backward finishes them: final norm; per layer L-1..0 its MLP block (w13, w2, both norm scales), and
+        # behind the lowest layer of every group the attention weights of that group; embedding (tied: finished last)
         self.buckets: list[tuple[str, int, int]] = []
         lo, _ = self._slices["norm"]
         self.buckets.append(("norm", lo, off))
+        mlp_lo = lambda l: self._slices[f"L{l}.w13"][0] if l < num_layers else self._slices["norm"][0]  # noqa: E731
+        attn_lo = lambda l: self._slices[f"L{l}.wqkv"][0] if l < num_layers else mlp_lo(0)  # noqa: E731
         for l in reversed(range(num_layers)):
-            lo = self._slices[f"L{l}.wqkv"][0]
-            hi = self._slices[f"L{l + 1}.wqkv"][0] if l + 1 < num_layers else self._slices["norm"][0]
-            self.buckets.append((f"L{l}", lo, hi))
-        self.buckets.append(("emb", 0, self._slices["L0.wqkv"][0] if num_layers else self._slices["norm"][0]))
+            self.buckets.append((f"L{l}.mlp", mlp_lo(l), mlp_lo(l + 1)))
+            if l % self.wgrad_group == 0:
+                self.buckets.append((f"attn.{l}", attn_lo(l), attn_lo(min(l + self.wgrad_group, num_layers))))
+        self.buckets.append(("emb", 0, attn_lo(0) if num_layers else self._slices["norm"][0]))
+        self._bucket_by_name = {b[0]: b for b in self.buckets}
+        self._bucket_group = self.wgrad_group
 
         # ---- torchtune-named parameters as views ------------------------------------------------------------------
         def view(name: str, rows: Optional[tuple[int, int]] = None, buf: Optional[Tensor] = None) -> Tensor:
@@ -377,12 +390,12 @@ class HipLlamaDecoder(nn.Module):
         ops.embed_fwd(tok, self._view("emb"), h, self.vocab_size)
         for l in range(L):
             sfx = f"{l}" if save else "x"
-            xn1 = A.get(f"xn1.{sfx}", (T, D), dt)
+            xn1 = A.get("xn1.all", (L, T, D), dt)[l] if save else A.get("xn1.x", (T, D), dt)  # saved per layer in ONE buffer: batched wgrads
             rstd1 = A.get(f"rstd1.{sfx}", (T,), torch.float32)
             ops.rmsnorm_fwd(h, self._view(f"L{l}.sa_norm"), xn1, rstd1, self.norm_eps)
             qkv = A.get(f"qkv.{sfx}", (T, self.qkv_dim), dt)
             ops.gemm_rope(xn1, self._view(f"L{l}.wqkv"), qkv, S, H + KV, hd, self._rope, positions=pos)  # RoPE in the GEMM epilogue
-            att = A.get(f"att.{sfx}", (T, H * hd), dt)
+            att = A.get("att.all", (L, T, H * hd), dt)[l] if save else A.get("att.x", (T, H * hd), dt)
             lse = A.get(f"lse.{sfx}", (B * H * S,), torch.float32)
             ops.attn_fwd(qkv, att, lse, B, S, H, KV, hd, ds, de)
             hmid = A.get(f"hmid.{sfx}", (T, D), dt)
@@ -433,6 +446,28 @@ class HipLlamaDecoder(nn.Module):
 
         sync = self.grad_sync if (self.grad_sync is not None and self.sync_this_backward) else None
         self._ensure_transposed()
+        announce = (lambda name: sync.bucket_ready(*self._bucket_by_name[name])) if sync else (lambda name: None)
+
+        # Weight gradients of the attention projections (dW_o = d hmid^T att: 64 output tiles; dW_qkv = d qkv^T xn1: 96): deferred until the
+        # lowest layer of a group has produced its d qkv, then ONE batched launch per weight covers the group at full K (8 layers: 512 and
+        # 768 tiles = 2 and 3 rounds of the 256 CUs) instead of a split-K launch + reduction per layer and weight.  Costs G x T x (D + qkv)
+        # elements of HBM for the group's output gradients (1.3 GB at the 1B shape, B x S = 16384) — memory this GPU has.
+        Gp = self.wgrad_group
+        if sync and Gp != self._bucket_group:
+            raise RuntimeError("wgrad_group was changed after construction: the data-parallel buckets were laid out for the old grouping")
+        defer = (Gp > 1 and dt == torch.bfloat16 and self._mfma_shapes() and T % 128 == 0 and T >= 256
+                 and ops.splitk_choice(D, H * hd, T) > 1 and ops.splitk_choice(self.qkv_dim, D, T) > 1)
+        xn1_all, att_all = A.get("xn1.all", (L, T, D), dt), A.get("att.all", (L, T, H * hd), dt)
+        if defer:
+            dhmid_all, dqkv_all = A.get("dh.b.all", (Gp, T, D), dt), A.get("dqkv.all", (Gp, T, self.qkv_dim), dt)
+            lstride = (self._slices["L1.wqkv"][0] - self._slices["L0.wqkv"][0]) if L > 1 else 0
+
+        def flush_attention_wgrads(l_lo: int) -> None:
+            n = min(Gp, L - l_lo)
+            g_o = torch.as_strided(G, (n, D, H * hd), (lstride, H * hd, 1), self._slices[f"L{l_lo}.wo"][0])
+            g_qkv = torch.as_strided(G, (n, self.qkv_dim, D), (lstride, D, 1), self._slices[f"L{l_lo}.wqkv"][0])
+            ops.gemm_batched(GEMM_TN, dhmid_all[:n], att_all[l_lo:l_lo + n], g_o, accumulate=acc)
+            ops.gemm_batched(GEMM_TN, dqkv_all[:n], xn1_all[l_lo:l_lo + n], g_qkv, accumulate=acc)
 
         def dgrad(dy: Tensor, name: str, dx: Tensor) -> None:
             """dx = dy @ W  (W = [out, in]); NT form on the [in, out] copy where one is kept."""
@@ -444,11 +479,10 @@ class HipLlamaDecoder(nn.Module):
         dh = A.get("dh.a", (T, D), dt)
         ops.rmsnorm_bwd(d_hn, A.get(f"h{L}", (T, D), dt), self.norm.scale, A.get("rstdf", (T,), torch.float32), None, dh,
                         gv("norm"), ws, accumulate=acc)
-        if sync:
-            sync.bucket_ready(*self.buckets[0])
+        announce("norm")
         for l in reversed(range(L)):
-            xn1, xn2 = A.get(f"xn1.{l}", (T, D), dt), A.get(f"xn2.{l}", (T, D), dt)
-            qkv, att = A.get(f"qkv.{l}", (T, self.qkv_dim), dt), A.get(f"att.{l}", (T, H * hd), dt)
+            xn1, xn2 = xn1_all[l], A.get(f"xn2.{l}", (T, D), dt)
+            qkv, att = A.get(f"qkv.{l}", (T, self.qkv_dim), dt), att_all[l]
             hmid, gu, act = A.get(f"hmid.{l}", (T, D), dt), A.get(f"gu.{l}", (T, 2 * I), dt), A.get(f"act.{l}", (T, I), dt)
             h_in = A.get(f"h{l}", (T, D), dt)
             # MLP: h_out = hmid + act @ w2^T
@@ -461,31 +495,35 @@ class HipLlamaDecoder(nn.Module):
             dxn = A.get("dxn", (T, D), dt)
             dgrad(dgu, f"L{l}.w13", dxn)
             wgrad(dgu, xn2, f"L{l}.w13")
-            dhmid = A.get("dh.b", (T, D), dt)
+            dhmid = dhmid_all[l % Gp] if defer else A.get("dh.b", (T, D), dt)
             ops.rmsnorm_bwd(dxn, hmid, self._view(f"L{l}.mlp_norm"), A.get(f"rstd2.{l}", (T,), torch.float32), dh, dhmid,
                             gv(f"L{l}.mlp_norm"), ws, accumulate=acc)
             # attention: hmid = h_in + att @ wo^T
             datt = A.get("datt", (T, H * hd), dt)
             dgrad(dhmid, f"L{l}.wo", datt)
-            wgrad(dhmid, att, f"L{l}.wo")
-            dqkv = A.get("dqkv", (T, self.qkv_dim), dt)
+            if not defer:
+                wgrad(dhmid, att, f"L{l}.wo")
+            dqkv = dqkv_all[l % Gp] if defer else A.get("dqkv", (T, self.qkv_dim), dt)
             delta = A.get("delta", (B * H * S,), torch.float32)
             # attention backward with the backward of the RoPE rotation fused into its epilogues: dqkv arrives in pre-RoPE space
             ops.attn_bwd(qkv, att, datt, A.get(f"lse.{l}", (B * H * S,), torch.float32), dqkv, delta, B, S, H, KV, hd, ds, de,
                          rope_table=self._rope, positions=pos)
             dgrad(dqkv, f"L{l}.wqkv", dxn)
-            wgrad(dqkv, xn1, f"L{l}.wqkv")
+            if not defer:
+                wgrad(dqkv, xn1, f"L{l}.wqkv")
             ops.rmsnorm_bwd(dxn, h_in, self._view(f"L{l}.sa_norm"), A.get(f"rstd1.{l}", (T,), torch.float32), dhmid, dh,
                             gv(f"L{l}.sa_norm"), ws, accumulate=acc)
-            if sync:
-                sync.bucket_ready(*self.buckets[1 + (L - 1 - l)])
+            announce(f"L{l}.mlp")
+            if defer and l % Gp == 0:
+                flush_attention_wgrads(l)
+            if l % self._bucket_group == 0:
+                announce(f"attn.{l}")
         ws_e = A.get("ws.emb", (max(_lib.load().ssi_embed_bwd_workspace_bytes(self.vocab_size), 16),), torch.uint8)
         if not acc and not self._emb_grad_written:  # backward through the hidden states only (no tied head in front): the scatter-add
             gv("emb").zero_()                       # below touches only the rows of this batch's tokens
         ops.embed_bwd(tok, dh, gv("emb"), self.vocab_size, ws_e)
         self._grads_dirty, self._grads_stale, self._emb_grad_written = True, False, False
-        if sync:
-            sync.bucket_ready(*self.buckets[-1])
+        announce("emb")
         self._saved = None
         self.attach_grads()
 

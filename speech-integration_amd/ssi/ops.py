@@ -218,6 +218,29 @@ def gemm_splitk(layout: int, a: Tensor, b: Tensor, c: Tensor, splits: int, works
                                       workspace.numel() * workspace.element_size(), stream_ptr()), "ssi_gemm_splitk")
 
 
+def gemm_batched(layout: int, a: Tensor, b: Tensor, c: Tensor, *, alpha: float = 1.0, alpha_dev: Tensor | None = None,
+                 accumulate: bool = False) -> None:
+    """c[i] = (accumulate ? c[i] : 0) + alpha * op(a[i]) op(b[i]) for every i of the leading dimension, ONE launch on the MFMA path.
+    3-D operands with unit inner stride; the leading (batch) stride is free, so ``c`` may be a strided view of the flat gradient."""
+    assert a.dim() == 3 and b.dim() == 3 and c.dim() == 3 and a.shape[0] == b.shape[0] == c.shape[0]
+    assert a.stride(2) == 1 and b.stride(2) == 1 and c.stride(2) == 1 and a.dtype == b.dtype == c.dtype
+    n, M, N = c.shape
+    if layout == GEMM_NT:
+        K = a.shape[2]
+        assert a.shape[1] == M and b.shape[1:] == (N, K)
+    elif layout == GEMM_NN:
+        K = a.shape[2]
+        assert a.shape[1] == M and b.shape[1:] == (K, N)
+    else:
+        K = a.shape[1]
+        assert a.shape[2] == M and b.shape[1:] == (K, N)
+    if alpha_dev is not None:
+        assert alpha_dev.dtype == torch.float32 and alpha_dev.numel() == 1
+    check(_lib.load().ssi_gemm_batched(layout, n, M, N, K, ptr(a), a.stride(1), a.stride(0), ptr(b), b.stride(1), b.stride(0), ptr(c),
+                                       c.stride(1), c.stride(0), alpha, ptr(alpha_dev), int(accumulate), dtype_code(c.dtype), stream_ptr()),
+          "ssi_gemm_batched")
+
+
 def gemm_swiglu_fwd(x: Tensor, w13: Tensor, gu: Tensor, act: Tensor) -> None:
     """gu = x @ w13^T ([gate | up]); act = silu(gate) * up — one launch on the MFMA path."""
     M, K = x.shape

@@ -193,6 +193,39 @@ def test_gemm_at_the_training_step_shapes_is_exact_on_integers(what, layout, M, 
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("what,M,N", [("dW_o x 8 layers", 2048, 2048), ("dW_qkv x 8 layers", 3072, 2048)])
+def test_batched_weight_gradients_at_the_step_shape_are_exact_on_integers(what, M, N):
+    """The deferred attention-projection weight gradients of a group of 8 layers as the model launches them (ssi_gemm_batched, K = 16384
+    tokens, outputs strided through the flat gradient buffer): exact on sparse integers, plain and accumulate form."""
+    from ssi import _lib, ops
+    n, K = 8, 16384
+    p = math.sqrt(4096.0 / K)
+    a, b = _sparse_ints((n, K, M), p, 201), _sparse_ints((n, K, N), p, 202)
+    ref = torch.bmm(a.float().transpose(1, 2), b.float())
+    exact = ref.abs() <= 256
+    assert float(exact.float().mean()) > 0.99
+    stride = M * N + 5120 * 2048           # the other projection's gradient lies between two layers' outputs
+    flat = torch.full((n * stride,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    c = torch.as_strided(flat, (n, M, N), (stride, N, 1), 0)
+    prev = ops.set_impl(_lib.IMPL_MFMA)
+    try:
+        ops.gemm_batched(2, a, b, c)
+        assert bool(((c.float() == ref) | ~exact).all()), f"{what}: not exact"
+        assert bool(torch.isnan(torch.as_strided(flat, (n, stride - M * N), (stride, 1), M * N)).all())  # nothing written between the outputs
+        c0 = torch.randint(-2, 3, (n, M, N), device=DEV, generator=torch.Generator(device=DEV).manual_seed(203)).to(torch.bfloat16)
+        c.copy_(c0)
+        alpha = torch.tensor([0.5], dtype=torch.float32, device=DEV)
+        ops.gemm_batched(2, a, b, c, alpha_dev=alpha, accumulate=True)
+        want = (0.5 * ref).bfloat16().float() + c0.float()
+        ok = exact & ((0.5 * ref) == (0.5 * ref).bfloat16().float()) & (want == want.bfloat16().float())
+        assert float(ok.float().mean()) > 0.5
+        assert bool(((c.float() == want) | ~ok).all()), f"{what}: accumulate form not exact"
+    finally:
+        ops.set_impl(prev)
+        del a, b, ref, exact, flat, c
+        torch.cuda.empty_cache()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # 3. Attention at S = 4096 / 8192 with the model's head counts
 # ---------------------------------------------------------------------------------------------------------------------

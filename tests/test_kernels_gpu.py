@@ -694,6 +694,55 @@ def test_gemm_splitk_weight_gradient_on_the_persistent_kernel(ops, splits, accum
     assert float(diff.max()) <= 2 ** -6 * float(direct.float().abs().max())
 
 
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_gemm_batched_weight_gradients_equal_one_call_per_problem(ops, accumulate):
+    """ssi_gemm_batched (TN, persistent kernel): `batch` problems in one launch, C a strided view (the model's flat gradient buffer with
+    other weights between the problems).  Same K loop per tile as ssi_gemm -> bit-identical to one ssi_gemm per problem; exact on integers."""
+    n, M, N, K = 5, 512, 768, 1024         # 5 x 6 tiles: problems end inside the XCD spans and inside a round
+    g = torch.Generator().manual_seed(77)
+    a = torch.randn(n, K, M, generator=g).bfloat16().to(DEV)
+    b = torch.randn(n, K, N, generator=g).bfloat16().to(DEV)
+    gap = 1000 * 8                         # elements between the problems' outputs (other parameters in the flat buffer)
+    flat0 = torch.randn(n * (M * N + gap), generator=g).bfloat16().to(DEV)
+    flat1, flat2 = flat0.clone(), flat0.clone()
+    view = lambda f: torch.as_strided(f, (n, M, N), (M * N + gap, N, 1), 0)  # noqa: E731
+    alpha = torch.tensor([0.25], device=DEV)
+    ops.gemm_batched(2, a, b, view(flat1), alpha_dev=alpha, accumulate=accumulate)
+    for i in range(n):
+        ops.gemm(2, a[i], b[i], view(flat2)[i], alpha_dev=alpha, accumulate=accumulate)
+    assert torch.equal(flat1, flat2)                                            # results AND the gaps (nothing written outside the views)
+    ref = torch.bmm(a.float().transpose(1, 2), b.float()) * 0.25
+    want = ref.bfloat16().float() + (view(flat0).float() if accumulate else 0)
+    torch.testing.assert_close(view(flat1).float(), want.bfloat16().float(), rtol=2e-2, atol=0.05 * math.sqrt(K))
+    ai = torch.randint(-2, 3, (n, K, M), generator=g).bfloat16().to(DEV)
+    bi = torch.randint(-2, 3, (n, K, N), generator=g).bfloat16().to(DEV)
+    ci = torch.full((n, M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm_batched(2, ai, bi, ci, alpha=2.0 ** -4)
+    refi = torch.bmm(ai.float().transpose(1, 2), bi.float()) * 2.0 ** -4
+    exact = refi.abs() <= 16
+    assert float(exact.float().mean()) > 0.9 and torch.equal(ci.float()[exact], refi[exact])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_batched_other_shapes_run_problem_by_problem(ops, dtype, layout):
+    """Layouts / dtypes / shapes the batched MFMA form does not take (fp32, NT / NN, ragged sizes, batch 1 and 0): a loop over ssi_gemm."""
+    n, M, N, K = 3, 70, 130, 33
+    shp_a = (n, M, K) if layout < 2 else (n, K, M)
+    shp_b = (n, N, K) if layout == 0 else (n, K, N)
+    a, b = rnd(*shp_a, dtype=dtype, seed=5).to(DEV), rnd(*shp_b, dtype=dtype, seed=6).to(DEV)
+    c = torch.full((n, M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm_batched(layout, a, b, c)
+    af, bf = a.float().cpu(), b.float().cpu()
+    A = af if layout < 2 else af.transpose(1, 2)
+    Bm = bf.transpose(1, 2) if layout == 0 else bf
+    torch.testing.assert_close(c.float().cpu(), torch.bmm(A, Bm), **(dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=0.1)))
+    one = torch.full((1, M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm_batched(layout, a[:1], b[:1], one)
+    assert torch.equal(one[0], c[0])
+    ops.gemm_batched(layout, a[:0], b[:0], c[:0])   # empty batch: nothing to do
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,cols", [(64, 64), (200, 136), (2048, 3072)])
 def test_transpose(ops, dtype, rows, cols):

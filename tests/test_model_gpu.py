@@ -322,6 +322,35 @@ def test_bf16_mfma_shaped_model_matches_oracle(transposed_copies):
     assert l2.item() < loss.item()  # the step reduced the loss on the same batch
 
 
+def test_deferred_batched_attention_weight_gradients_equal_the_per_layer_ones():
+    """The weight gradients of the attention projections are computed for a group of layers in one batched launch after the group's
+    lowest layer (model.wgrad_group; 3 layers in groups of 2 = one full and one partial group).  Against the same model computing
+    them per layer (split-K): every other gradient bit-equal, these two within a bf16 rounding of the fp32 sums; also when a second
+    micro-batch accumulates on top."""
+    from oracle import hf_crosscheck as hx
+    from ssi.loss import CEWithChunkedOutputLoss, compute_loss
+    from ssi.model import HipLlamaDecoder
+    params = dict(vocab_size=700, num_layers=3, num_heads=4, num_kv_heads=2, embed_dim=256, max_seq_len=512, intermediate_dim=512)
+    sd = hx.seeded_state_dict(params, 31)
+    batches = [_to_dev(hx.seeded_batch(700, 2, 128, 31 + i)) for i in range(2)]
+    grads = {}
+    for group in (2, 1):
+        model = HipLlamaDecoder(**params, dtype=torch.bfloat16, device=DEV)
+        model.wgrad_group = group
+        model.load_state_dict(sd)
+        for b in batches:
+            compute_loss(b, model, CEWithChunkedOutputLoss()).backward()
+        grads[group] = {k: p.grad.float().clone() for k, p in model.named_parameters()}
+        used = set(model._arena.buf)
+        assert ("dqkv.all" in used) == (group > 1)
+    for k, g in grads[2].items():
+        if any(t in k for t in ("q_proj", "k_proj", "v_proj", "output_proj")):
+            diff = (g - grads[1][k]).abs()
+            assert float(diff.max()) <= 2 ** -6 * float(grads[1][k].abs().max()), k
+        else:
+            assert torch.equal(g, grads[1][k]), k
+
+
 def test_hf_format_checkpoint_loads_into_the_hip_model_and_matches_hf_llama(tmp_path):
     """SURVEY.md §8f rank 3, end to end: a randomly initialised HF ``LlamaForCausalLM`` (built from a local config, no hub) is
     written as an HF model directory (sharded safetensors + config.json), read back through ``FullModelHFCheckpointer`` (key map

@@ -15,5 +15,5 @@ echo "write done"
 stats=$(ls gpurun_out/${tag}_prof/*/*kernel_stats.csv | head -1)
 cp "$stats" gpurun_out/${tag}_bench_kernel_stats.csv
 python tools/prof_summary.py gpurun_out/${tag}_bench_kernel_stats.csv gpurun_out/${tag}_bench_kernel_stats.md "${tag}: python bench.py --no-cpu-baseline (20 timed + 5 warm-up steps) under rocprofv3 --kernel-trace --stats" 25
-python tools/pmc_traffic.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write "gemm_nt4dma_kernel<true, true, 0, 0, false>" gpurun_out/${tag}_traffic.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-timing"
+python tools/pmc_traffic.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write "gemm_nt4dma_kernel<true, true, 0, 0, false, false>" gpurun_out/${tag}_traffic.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-timing"
 tail -c 600 gpurun_out/${tag}_bench.json
