@@ -549,9 +549,37 @@ class HipLlamaDecoder(nn.Module):
             ops.gemm(GEMM_NT, dlogits, self._view_t("emb"), d_hn, alpha_dev=alpha_dev)
         else:
             ops.gemm(GEMM_NN, dlogits, self._view("emb"), d_hn, alpha_dev=alpha_dev)
-        ops.gemm(GEMM_TN, dlogits, hn, self._view("emb", None, self._flat_grad), alpha_dev=alpha_dev, accumulate=acc)
+        g_emb = self._view("emb", None, self._flat_grad)
+        # dE = dlogits^T hn has vocab_pad / 256 x D / 256 output tiles (521 x 8 = 4168 at V = 133 258): 16 full rounds of the 256 CUs and a
+        # 17th with 72 tiles, each a full K = T contraction (~360 us with 184 CUs idle).  The rows of the last partial round go to a second
+        # launch that also splits K, so that the tail occupies the chip for a third of a tile's time.
+        rows_main = self._head_wgrad_main_rows(T)
+        if rows_main:
+            Vp = self.vocab_pad
+            ops.gemm(GEMM_TN, dlogits[:, :rows_main], hn, g_emb[:rows_main], alpha_dev=alpha_dev, accumulate=acc)
+            tail, splits = Vp - rows_main, self._head_wgrad_tail_splits
+            wsk = self._arena.get("ws.splitk.head", (splits * tail * D,), torch.float32)
+            ops.gemm_splitk(GEMM_TN, dlogits[:, rows_main:], hn, g_emb[rows_main:], splits, wsk, alpha_dev=alpha_dev, accumulate=acc)
+        else:
+            ops.gemm(GEMM_TN, dlogits, hn, g_emb, alpha_dev=alpha_dev, accumulate=acc)
         self._emb_grad_written = True  # the decoder backward that follows adds the token rows on top and closes the window
         return d_hn
+
+    _head_wgrad_tail_splits = 3
+
+    def _head_wgrad_main_rows(self, T: int, n_cu: int = 256) -> int:
+        """Rows of the embedding gradient computed by the unsplit launch (whole rounds of the CUs); 0 = one launch for everything (not the
+        MFMA path, a last round at least half full, or a tail whose split units would not fit one round)."""
+        if os.environ.get("SSI_HEAD_WGRAD_TAIL", "1") == "0" or self.dtype != torch.bfloat16 or not self._mfma_shapes() or T % 128 or T < 64 * 6 * self._head_wgrad_tail_splits:
+            return 0
+        tm, tn = self.vocab_pad // 256, self.embed_dim // 256
+        full_rounds = (tm * tn) // n_cu
+        if full_rounds == 0 or (full_rounds * n_cu) % tn:
+            return 0
+        tail_tiles = tm * tn - full_rounds * n_cu
+        if tail_tiles == 0 or 2 * tail_tiles >= n_cu or tail_tiles * self._head_wgrad_tail_splits > n_cu:
+            return 0
+        return full_rounds * n_cu // tn * 256
 
     # ---- public API --------------------------------------------------------------------------------------------------
     def _check_inputs(self, tokens: Tensor, mask, encoder_input, encoder_mask, input_pos) -> Tensor:

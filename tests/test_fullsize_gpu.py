@@ -144,6 +144,7 @@ STEP_SHAPES = [
     ("LM head data gradient", 1, 16384, 2048, 133_376, 1),
     ("LM head weight gradient", 2, 133_376, 2048, 16384, 1),
     ("LM head weight gradient, V=130306 (config E)", 2, 130_560, 2048, 16384, 1),
+    ("LM head weight gradient, rows of the last partial round (split-K 3)", 2, 2304, 2048, 16384, 3),
     ("dW_qkv (split-K)", 2, 3072, 2048, 16384, 0),
     ("dW_o (split-K)", 2, 2048, 2048, 16384, 0),
     ("dW13", 2, 16384, 2048, 16384, 1),
@@ -165,9 +166,10 @@ def test_gemm_at_the_training_step_shapes_is_exact_on_integers(what, layout, M, 
     prev = ops.set_impl(_lib.IMPL_MFMA)   # the MFMA path or an error: no silent fallback to the generic kernel
     try:
         c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-        if splits == 0:
-            splits = ops.splitk_choice(M, N, K)
-            assert splits > 1, "the model splits this weight gradient over K"
+        if splits != 1:
+            if splits == 0:
+                splits = ops.splitk_choice(M, N, K)
+                assert splits > 1, "the model splits this weight gradient over K"
             ws = torch.empty(splits * M * N, dtype=torch.float32, device=DEV)
             ops.gemm_splitk(layout, a, b, c, splits, ws)
         else:

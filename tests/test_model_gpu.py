@@ -351,6 +351,32 @@ def test_deferred_batched_attention_weight_gradients_equal_the_per_layer_ones():
             assert torch.equal(g, grads[1][k]), k
 
 
+def test_head_weight_gradient_tail_round_is_split_over_k(monkeypatch):
+    """The tied head's weight gradient: output tiles beyond the last whole round of the 256 CUs go to a second, K-split launch
+    (HipLlamaDecoder._head_wgrad_main_rows).  Same gradients as the single launch up to the order of the fp32 partial sums; the rows of the
+    whole rounds bit-equal.  V = 67 500 -> 264 row tiles x 1 column tile = one round + 8 tiles."""
+    from oracle import hf_crosscheck as hx
+    from ssi.loss import CEWithChunkedOutputLoss, compute_loss
+    from ssi.model import HipLlamaDecoder
+    params = dict(vocab_size=67_500, num_layers=1, num_heads=4, num_kv_heads=2, embed_dim=256, max_seq_len=1024, intermediate_dim=512)
+    g = torch.Generator().manual_seed(5)
+    batch = _to_dev(hx.seeded_batch(67_500, 2, 640, 41))
+    grads = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("SSI_HEAD_WGRAD_TAIL", on)
+        torch.manual_seed(3)
+        model = HipLlamaDecoder(**params, dtype=torch.bfloat16, device=DEV)
+        with torch.no_grad():
+            model._flat.copy_((torch.randn(model._flat.numel(), generator=g.manual_seed(5)) * 0.05).to(torch.bfloat16))
+        assert model._head_wgrad_main_rows(1280) == (256 * 256 if on == "1" else 0)
+        compute_loss(batch, model, CEWithChunkedOutputLoss()).backward()
+        grads[on] = model.tok_embeddings.weight.grad.float().clone()
+        assert ("ws.splitk.head" in model._arena.buf) == (on == "1")
+    assert torch.equal(grads["1"][:65_536], grads["0"][:65_536])
+    diff = (grads["1"][65_536:] - grads["0"][65_536:]).abs()
+    assert float(grads["0"][65_536:].abs().max()) > 0 and float(diff.max()) <= 2 ** -6 * float(grads["0"].abs().max())
+
+
 def test_hf_format_checkpoint_loads_into_the_hip_model_and_matches_hf_llama(tmp_path):
     """SURVEY.md §8f rank 3, end to end: a randomly initialised HF ``LlamaForCausalLM`` (built from a local config, no hub) is
     written as an HF model directory (sharded safetensors + config.json), read back through ``FullModelHFCheckpointer`` (key map
