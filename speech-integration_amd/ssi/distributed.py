@@ -62,7 +62,13 @@ class GradSync:
         self._wait_events: list = []
         # token counts and the running loss travel on a communicator of their own: on the gradients' one they would queue behind
         # every bucket already issued (a communicator runs its collectives in issue order), the deferred embedding bucket included
-        self.scalar_group = dist.new_group() if self.enabled else None
+        self.scalar_group = None
+        if self.enabled:
+            try:
+                self.scalar_group = dist.new_group()
+            except Exception as e:  # a backend without communicator splitting: the scalars then share the gradients' communicator (slower, same result)
+                import logging
+                logging.getLogger(__name__).warning("GradSync: no second communicator for the scalar all-reduce (%r); using the default group", e)
         if flat_grad.is_cuda and self.enabled:
             # RCCL's kernels hold CUs for the length of a reduction while the backward GEMMs run: a persistent GEMM with a fixed
             # tile-to-workgroup map would wait a whole round for the workgroups that could not start (include/ssi_hip.h)
