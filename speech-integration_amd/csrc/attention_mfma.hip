@@ -588,6 +588,16 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
         }
     };
     int cur_qt = 0;  // query tile of the step being computed (steps run in order too)
+    // -DDKV_STAMP (debug build, tools/dkv_stamps.py): cycle totals of wave 0 per phase of a step, left in the workgroup's first dq row
+#ifdef DKV_STAMP
+    unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_readcyclecounter();
+    const unsigned long long st_begin = st_last;
+    int st_steps = 0;
+#define STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_last; st_last = now_; }
+#else
+#define STAMP(i)
+#endif
     // one step on ring buffer BUF (compile-time, so every LDS address is a hoisted per-lane base + an immediate)
     auto do_step = [&](int step, auto buf_c) {
         constexpr int BUF = decltype(buf_c)::value;
@@ -604,7 +614,11 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
             if (step + RING - 2 < n_steps) issue(step + RING - 2);
             if (step + RING - 1 < n_steps) issue(step + RING - 1);
         }
+        STAMP(0)  // wait + barrier + the two requests the barrier made room for
         if (q0 + 31 < key0 || q0 >= de_hi) return;  // wave-uniform: no query of the tile sees any key of this wave
+#ifdef DKV_STAMP
+        ++st_steps;
+#endif
         f32x16 sacc, pacc;  // rows = queries q0 + rowmap(r, h): row constants come in runs of 4
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -621,12 +635,17 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
             dfr[ks] = frag_row<SWZ_DUAL>(dt, 0, ks, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef DKV_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        STAMP(1)  // row constants + fragment reads landed
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ks], kf[ks], sacc, 0, 0, 0);
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[ks], vf[ks], pacc, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(2)  // S / dP MFMAs issued
         bf16x8 dtr[2][2], qtr[2][2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
@@ -636,6 +655,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
                 qtr[s2][db] = frag_tr<SWZ_DUAL>(qt, s2 * 16, db * 32, lane);
             }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(3)  // transposed reads issued
         if (q0 < key0 + 32 || q0 + 31 >= de_lo) {  // edge tile: keys beyond the query or of an earlier document contribute nothing
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -653,6 +673,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
                 pacc[r] *= p;
             }
         }
+        STAMP(4)  // exponentials (includes waiting for S / dP)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8 pf = acc_frag(sacc, s2), dsf = acc_frag(pacc, s2);
@@ -662,6 +683,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
                 dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtr[s2][db], dsf, dk[db], 0, 0, 0);
             }
         }
+        STAMP(5)  // conversions + dV / dK MFMAs issued
     };
 #pragma unroll
     for (int i = 0; i < RING - 2; ++i)
@@ -685,6 +707,15 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
             if (step + 9 < n_steps) do_step(step + 9, std::integral_constant<int, 9>{});
         }
     }
+#ifdef DKV_STAMP
+    if (lane == 0 && wave == 0) {  // DEBUG BUILD ONLY: overwrites the first floats of the workgroup's first dq row
+        float* dbg = reinterpret_cast<float*>(dqkv + (row0 + kgrp * 128) * ld);
+        for (int i = 0; i < 6; ++i) dbg[i] = (float)st_acc[i];
+        dbg[6] = (float)(__builtin_readcyclecounter() - st_begin);
+        dbg[7] = (float)st_steps;
+        dbg[8] = (float)n_steps;
+    }
+#endif
     // lane = key, registers = d (runs of 4): 8-byte stores into the k and v column blocks of dqkv
     bf16_t* krow_out = dqkv + (row0 + kg) * ld + (int64_t)H * HD + (int64_t)kvh * HD;
     bf16_t* vrow_out = krow_out + (int64_t)KV * HD;
