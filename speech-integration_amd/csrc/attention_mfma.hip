@@ -162,16 +162,24 @@ __device__ __forceinline__ void dma4(unsigned lds_dst, unsigned voff, u32x4 rs, 
 
 // K and V tiles (64 keys x 64 d each, 8 KiB + 8 KiB) of one (batch, kv head) into ring slots: each of the 4 waves moves two 1-KiB
 // pieces (8 rows x 128 B) of K and two of V = 4 requests per wave per tile.
+// Waves per workgroup of the forward and dQ kernels: 4 (one 32-query block x the 4 heads of a GQA group, two such workgroups per CU).  With 8
+// (-DATTN_NW=8: two query blocks share each K / V tile, every wave issues 2 LDS-DMA requests per tile instead of 4, one workgroup per CU) the
+// forward took 197-201 us against 179 and the backward 553-561 against 549: what the halved request count saves, the 8-wave barrier and the
+// loss of the second, unsynchronised workgroup cost again.
+#ifndef ATTN_NW
+#define ATTN_NW 4
+#endif
+constexpr int ANW = ATTN_NW, ANP = 8 / ATTN_NW;  // waves per workgroup, K (and V) pieces per wave and tile
 template <int SWZ_K, int SWZ_V> struct KvTileDma {
     u32x4 rs;             // base = K rows of the batch, column block of the kv head
-    unsigned vk[2], vv[2];  // per-lane source byte offsets of the two K and the two V pieces inside a tile
+    unsigned vk[ANP], vv[ANP];  // per-lane source byte offsets of this wave's K and V pieces inside a tile
     unsigned lds_piece;   // LDS byte address of this wave's first piece in slot 0
     unsigned tile_bytes;  // source bytes from one tile to the next
     __device__ __forceinline__ void init(const bf16_t* kbase, int64_t ld, int kv_cols, const char* smem, int wave, int lane) {
         rs = buffer_rsrc(kbase);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int row = (p * 4 + wave) * 8 + (lane >> 3);
+        for (int p = 0; p < ANP; ++p) {
+            const int row = (p * ANW + wave) * 8 + (lane >> 3);
             vk[p] = (unsigned)((row * ld + ((lane & 7) ^ swz<SWZ_K>(row)) * 8) * 2);
             vv[p] = (unsigned)((row * ld + kv_cols + ((lane & 7) ^ swz<SWZ_V>(row)) * 8) * 2);
         }
@@ -181,9 +189,9 @@ template <int SWZ_K, int SWZ_V> struct KvTileDma {
     __device__ __forceinline__ void tile(int t, unsigned slot_bytes) const {
         const unsigned soff = (unsigned)t * tile_bytes;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            dma16(lds_piece + slot_bytes + p * 4096, vk[p], rs, soff);
-            dma16(lds_piece + slot_bytes + 8192 + p * 4096, vv[p], rs, soff);
+        for (int p = 0; p < ANP; ++p) {
+            dma16(lds_piece + slot_bytes + p * ANW * 1024, vk[p], rs, soff);
+            dma16(lds_piece + slot_bytes + 8192 + p * ANW * 1024, vv[p], rs, soff);
         }
     }
 };
@@ -191,13 +199,13 @@ template <int SWZ_K, int SWZ_V> struct KvTileDma {
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
-// grid.x = B * KV * (S / (32 * QPW)),  QPW = 4 / rep q-blocks per workgroup; wave w: head kvh*rep + w % rep, q-block w / rep
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t ld, bf16_t* __restrict__ out,
+// grid.x = B * KV * (S / (32 * QPW)),  QPW = ANW / rep q-blocks per workgroup; wave w: head kvh*rep + w % rep, q-block w / rep
+__global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t ld, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, const int32_t* __restrict__ doc_start, int S, int H,
                                                        int KV) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 2 * 8192];  // ring of 3 x [K | V][64][64] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rep = H / KV, qpw = 4 / rep;
+    const int rep = H / KV, qpw = ANW / rep;
     const int nqb = S / (32 * qpw);
     // heavy q-blocks first
     int rank_, pair_;
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         constexpr int BUF = decltype(buf_c)::value;  // compile-time ring slot: LDS addresses = hoisted lane base + immediate
         const char* kt = smem + BUF * 16384;
         const char* vt = kt + 8192;
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // own pieces of tile t landed (tile t+1 may fly)
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ANP) : "memory");  // own pieces of tile t landed (tile t+1 may fly)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ring_barrier();  // everybody's pieces landed; the slot of tile t-1 is free again
         if (t + 2 < nt) kvdma.tile(t + 2, ((BUF + 2) % 3) * 16384);
@@ -351,14 +359,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 // =====================================================================================================================
 // backward: dQ   (same decomposition as the forward)
 // =====================================================================================================================
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ out,
+__global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, bf16_t* __restrict__ dqkv,
                                                           const int32_t* __restrict__ doc_start, const float* __restrict__ rope,
                                                           const int32_t* __restrict__ positions, int S, int H, int KV) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 2 * 8192];  // ring of 3 x [K | V][64][64] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rep = H / KV, qpw = 4 / rep;
+    const int rep = H / KV, qpw = ANW / rep;
     const int nqb = S / (32 * qpw);
     int rank_, pair_;
     block_to_work(nqb, (int)(gridDim.x / nqb), rank_, pair_);
@@ -409,6 +417,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
+    // -DDQ_STAMP (debug build, tools/dkv_stamps.py dq): cycle totals of wave 0 per phase of a tile, left in the wave's first dq row
+#ifdef DQ_STAMP
+    unsigned long long qs_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long qs_last = __builtin_readcyclecounter();
+    const unsigned long long qs_begin = qs_last;
+    int qs_tiles = 0;
+#define QSTAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); qs_acc[i] += now_ - qs_last; qs_last = now_; }
+#else
+#define QSTAMP(i)
+#endif
     KvTileDma<SWZ_DUAL, SWZ_ROW> kvdma;
     kvdma.init(kbase, ld, KV * HD, smem, wave, lane);
     kvdma.tile(t_first, 0);
@@ -417,12 +435,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         constexpr int BUF = decltype(buf_c)::value;
         const char* kt = smem + BUF * 16384;
         const char* vt = kt + 8192;
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // own pieces of tile t landed (tile t+1 may fly)
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ANP) : "memory");  // own pieces of tile t landed (tile t+1 may fly)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ring_barrier();  // everybody's pieces landed; the slot of tile t-1 is free again
         if (t + 2 < nt) kvdma.tile(t + 2, ((BUF + 2) % 3) * 16384);
+        QSTAMP(0)  // wait + barrier + the 4 requests of tile t+2
         const int k0 = t * 64;
         if (k0 <= q0 + 31 && k0 + 63 >= ds_lo) {
+#ifdef DQ_STAMP
+            ++qs_tiles;
+#endif
             // fragment reads ahead of the products that use them (see attn_fwd_kernel)
             bf16x8 kfr[2][4], vfr[2][4];
 #pragma unroll
@@ -433,6 +455,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                     vfr[kb][ks] = frag_row<SWZ_ROW>(vt, kb * 32, ks, lane);
                 }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef DQ_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            QSTAMP(1)  // 16 row-fragment reads landed
             f32x16 sacc[2], pacc[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -446,12 +472,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                     pacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb][ks], dof[ks], pacc[kb], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
+            QSTAMP(2)  // 16 S / dP MFMAs issued
             bf16x8 ktr[4][2];
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int db = 0; db < 2; ++db) ktr[s][db] = frag_tr<SWZ_DUAL>(kt, s * 16, db * 32, lane);
             __builtin_amdgcn_sched_barrier(0);
+            QSTAMP(3)  // 16 transposed reads issued
             if (k0 + 63 > q0 || k0 < ds_hi) {  // edge tile: keys beyond the query or before its document contribute nothing
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -468,6 +496,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sacc[kb][r] = __builtin_amdgcn_exp2f(sacc[kb][r] * LOG2E) * pacc[kb][r];
             }
+            QSTAMP(4)  // exponentials (includes waiting for S / dP)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bf16x8 dsf = acc_frag(sacc[s >> 1], s & 1);
@@ -475,6 +504,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                 for (int db = 0; db < 2; ++db)
                     dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[s][db], dsf, dq[db], 0, 0, 0);
             }
+            QSTAMP(5)  // conversions + 8 dQ MFMAs issued
         }
     };
     for (int t = t_first; t < nt; t += 3) {
@@ -483,6 +513,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         if (t + 2 < nt) tile_step(t + 2, std::integral_constant<int, 2>{});
     }
     bf16_t* drow = dqkv + (row0 + qg) * ld + (int64_t)head * HD;
+#ifdef DQ_STAMP
+    unsigned long long qs_total = __builtin_readcyclecounter() - qs_begin;
+#endif
     // rope != NULL: the gradient leaves in pre-RoPE space (backward of the rotation fused here, saves a pass over dqkv)
     const float* tb = rope ? rope + (int64_t)(positions ? positions[row0 + qg] : qg) * HD : nullptr;
 #pragma unroll
@@ -495,6 +528,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
             if (tb) v = unrope4(v, tb, db * 32 + 8 * g + 4 * h);
             *reinterpret_cast<bf16x4*>(drow + db * 32 + 8 * g + 4 * h) = v;
         }
+#ifdef DQ_STAMP
+    if (wave == 0) {  // DEBUG BUILD ONLY: lane 0's row of head `head` carries the totals (overwrites the gradient there)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            float* dbg = reinterpret_cast<float*>(drow);
+            for (int i = 0; i < 6; ++i) dbg[i] = (float)qs_acc[i];
+            dbg[6] = (float)qs_total;
+            dbg[7] = (float)qs_tiles;
+            dbg[8] = (float)(nt - t_first);
+        }
+    }
+#endif
 }
 
 // =====================================================================================================================
@@ -742,7 +787,8 @@ bool ssi_attn_mfma_supported(int64_t ld, int64_t batch, int64_t seq, int n_heads
     if (dtype != SSI_BF16 || head_dim != HD) return false;
     const int rep = n_heads / n_kv;
     if (rep != 1 && rep != 2 && rep != 4) return false;
-    if (seq < 128 || seq % 128 != 0) return false;  // q-block group of up to 128 rows, 64-key tiles
+    const int wg_rows = 32 * ANW / rep < 128 ? 128 : 32 * ANW / rep;  // query rows per forward workgroup; dK/dV: 128-key groups
+    if (seq < wg_rows || seq % wg_rows != 0) return false;
     if (ld % 8 != 0 || batch <= 0) return false;
     if (batch * n_kv * (seq / 32) > (1LL << 30)) return false;
     return true;
@@ -750,9 +796,9 @@ bool ssi_attn_mfma_supported(int64_t ld, int64_t batch, int64_t seq, int n_heads
 
 int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, const int32_t* doc_start, int64_t batch, int64_t seq,
                       int n_heads, int n_kv, void* stream) {
-    const int rep = n_heads / n_kv, qpw = 4 / rep;
+    const int rep = n_heads / n_kv, qpw = ANW / rep;
     const unsigned grid = (unsigned)(batch * n_kv * (seq / (32 * qpw)));
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)out, lse,
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(grid), dim3(64 * ANW), 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)out, lse,
                        doc_start, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
     return SSI_OK;
@@ -762,8 +808,8 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
                       const int32_t* doc_start, const int32_t* doc_end, const float* rope, const int32_t* positions, int64_t batch,
                       int64_t seq, int n_heads, int n_kv, void* stream) {
     auto st = (hipStream_t)stream;
-    const int rep = n_heads / n_kv, qpw = 4 / rep;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * n_kv * (seq / (32 * qpw)))), dim3(256), 0, st, (const bf16_t*)qkv,
+    const int rep = n_heads / n_kv, qpw = ANW / rep;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * n_kv * (seq / (32 * qpw)))), dim3(64 * ANW), 0, st, (const bf16_t*)qkv,
                        ld, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_start, rope, positions, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(batch * n_kv * (seq / 128))), dim3(256), 0, st, (const bf16_t*)qkv, ld,

@@ -12,6 +12,16 @@ dqkv = torch.empty_like(qkv); delta = torch.empty_like(lse)
 ops.attn_fwd(qkv, out, lse, B, S, H, KV, hd)
 for _ in range(3): ops.attn_bwd(qkv, out, dout, lse, dqkv, delta, B, S, H, KV, hd)
 torch.cuda.synchronize()
+if len(sys.argv) > 1 and sys.argv[1] == "dq":   # -DDQ_STAMP build: wave 0 (head kvh*4) of each q-block workgroup, row q0
+    qn = ["wait+barrier+DMA issue", "row frag reads landed", "S/dP MFMAs issued", "tr reads issued", "exponentials (+wait S/dP)", "cvt + dQ MFMAs issued"]
+    for b in (0, 3):
+        for qb in (63, 32, 8):
+            row = dqkv[b * S + qb * 32].view(torch.uint8)[:36].view(torch.float32).tolist()
+            tiles, nt, total = row[7], row[8], row[6]
+            if tiles <= 0: continue
+            print(f"batch {b} q-block {qb:2d}: {int(nt)} tiles ({int(tiles)} active), {total / nt:7.0f} cycles per tile; per ACTIVE tile: " +
+                  ", ".join(f"{n} {row[i] / tiles:5.0f}" for i, n in enumerate(qn)))
+    sys.exit(0)
 names = ["wait+barrier+DMA issue", "frag reads landed", "S/dP MFMAs issued", "tr reads issued", "exponentials (+wait S/dP)", "cvt + dV/dK MFMAs issued"]
 for b in (0, 3):
     for g in (0, 4, 8, 15):
