@@ -635,8 +635,10 @@ extern "C" int ssi_adamw_step(void* param, void* grad, void* exp_avg, void* exp_
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    // 20 GB touched once: non-temporal accesses and many short blocks measured 6 % faster than 8192 long-lived ones (tools/lab)
-    SSI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(adamw_kernel<T>, dim3(stream_grid(n / Vec16<T>::N + 1, 32768)), dim3(256), 0,
+    // 17 GB touched once: non-temporal accesses and as many short blocks as there are 16-byte vectors (no grid-stride loop at the model's
+    // size: 608 k blocks).  tools/adamw_bench.py, 1.246 G bf16 parameters: 8192 long-lived blocks 5.5 TB/s, 32768 6.2, 131072 6.3, one vector
+    // per thread 6.47 TB/s (2.70 ms); two vectors per thread with all eight loads in flight first: 6.1
+    SSI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(adamw_kernel<T>, dim3(stream_grid(n / Vec16<T>::N + 1, 1 << 20)), dim3(256), 0,
                                                  (hipStream_t)stream, (T*)param, (T*)grad, (T*)exp_avg, (T*)exp_avg_sq, n,
                                                  lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
                                                  grad_scale_dev, zero_grad));
