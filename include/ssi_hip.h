@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define SSI_ABI_VERSION 4 /* 4: + ssi_gemm_batched
+#define SSI_ABI_VERSION 5 /* 5: ssi_doc_ranges takes n_clamped (out-of-table positions are counted, not only clamped)
+                           * 4: + ssi_gemm_batched
                            * 2: + ssi_attn_varlen_fwd/bwd(_rope), ssi_set_gemm_tile_order, NN form of ssi_gemm_swiglu_bwd
                            * 3: ssi_ce_reduce takes `vocab` and reports out-of-range labels in out[3]; + ssi_doc_ranges; ssi_rmsnorm_bwd takes accumulate_dscale; + ssi_lmhead_ce_fwd/bwd */
 
@@ -115,9 +116,11 @@ int ssi_attn_varlen_bwd(const void* qkv, int64_t ld, const void* out, const void
 
 /* input_pos [batch, seq] (int64; restarts at 0 with every document of a packed row) -> the int32 [batch*seq] arrays the varlen entries
  * take: positions (clamped to [0, max_pos]: the RoPE table is never indexed past its end), doc_start, doc_end.  Position 0 of a row
- * always starts a document.  One launch (the reference has no packed path: ssi/data/__init__.py:66-73 raises). */
+ * always starts a document.  n_clamped (may be NULL): one int32 the kernel ADDS the number of positions outside [0, max_pos] to — the
+ * caller zeroes it and reads it with whatever it reads back anyway, so that a data bug is reported instead of silently clamped.
+ * One launch (the reference has no packed path: ssi/data/__init__.py:66-73 raises). */
 int ssi_doc_ranges(const int64_t* input_pos, int64_t batch, int64_t seq, int64_t max_pos, int32_t* positions, int32_t* doc_start,
-                   int32_t* doc_end, void* stream);
+                   int32_t* doc_end, int32_t* n_clamped, void* stream);
 
 /* Same, followed by the backward of the RoPE rotation on the q and k heads of dqkv (= ssi_rope_inplace(dqkv, ..., inverse=1)): the
  * MFMA kernels apply it in their epilogues, which saves a pass over dqkv.  rope_table / table_len / positions as in ssi_rope_inplace. */

@@ -474,7 +474,7 @@ extern "C" int ssi_count_tokens(const int64_t* tokens, const int64_t* labels, in
 // =====================================================================================================================
 __global__ __launch_bounds__(256) void doc_ranges_kernel(const int64_t* __restrict__ input_pos, int64_t seq, int max_pos,
                                                          int32_t* __restrict__ pos, int32_t* __restrict__ doc_start,
-                                                         int32_t* __restrict__ doc_end) {
+                                                         int32_t* __restrict__ doc_end, int32_t* __restrict__ n_clamped) {
     __shared__ int last_start[256], first_start[256];
     const int64_t row = blockIdx.x;
     const int64_t* ip = input_pos + row * seq;
@@ -494,13 +494,15 @@ __global__ __launch_bounds__(256) void doc_ranges_kernel(const int64_t* __restri
     int after = (int)seq;        // first start in the spans after mine
     for (int u = t + 1; u < 256 && after == (int)seq; ++u) after = first_start[u];
     // forward: document start of every position of my span
-    int cur = before;
+    int cur = before, clamped = 0;
     for (int s = lo; s < hi; ++s) {
         if (s == 0 || ip[s] == 0) cur = s;
         doc_start[row * seq + s] = cur;
         const int64_t p = ip[s];
+        clamped += (p < 0 || p > max_pos) ? 1 : 0;
         pos[row * seq + s] = (int32_t)(p < 0 ? 0 : (p > max_pos ? max_pos : p));
     }
+    if (n_clamped && clamped) atomicAdd(n_clamped, clamped);  // integer: exact whatever the order
     // backward: one past the last position of the document = the first start strictly after s
     int nxt = after;
     for (int s = hi - 1; s >= lo; --s) {
@@ -510,11 +512,11 @@ __global__ __launch_bounds__(256) void doc_ranges_kernel(const int64_t* __restri
 }
 
 extern "C" int ssi_doc_ranges(const int64_t* input_pos, int64_t batch, int64_t seq, int64_t max_pos, int32_t* positions,
-                              int32_t* doc_start, int32_t* doc_end, void* stream) {
+                              int32_t* doc_start, int32_t* doc_end, int32_t* n_clamped, void* stream) {
     SSI_CHECK_ARG(input_pos && positions && doc_start && doc_end && batch >= 0 && seq >= 0 && seq < (1LL << 31) && max_pos >= 0 && max_pos < (1LL << 31));
     if (batch == 0 || seq == 0) return SSI_OK;
     hipLaunchKernelGGL(doc_ranges_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, input_pos, seq, (int)max_pos, positions,
-                       doc_start, doc_end);
+                       doc_start, doc_end, n_clamped);
     SSI_LAUNCH_CHECK();
     return SSI_OK;
 }

@@ -306,6 +306,9 @@ __global__ __launch_bounds__(1024, 4) void ce_row_bf16_kernel(bf16_t* __restrict
             for (int c = 0; c < NCH; ++c)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) m = fmaxf(m, fmaxf(lo(x[c][d]), hi(x[c][d])));
+            // thread 0's label logit must have LANDED before any wave may overwrite that address with the gradient: the barrier inside
+            // block_max only orders issue.  Free here: the row registers the max just consumed were the only other loads in flight.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const float gm = block_max(m, red);
             opaque();
             const float nm = -gm * LOG2E;

@@ -34,12 +34,14 @@ def resolve_checkpointer_output_dir(cfg, wandb_logger) -> str:
 
 
 def save_rng_states() -> dict[str, Any]:
-    """Python / NumPy / torch generator states under the reference's keys (``/root/reference/ssi/checkpoint.py:188-197``).  The NumPy
-    Mersenne-Twister key array is stored as a tensor so that ``training_state.pt`` holds nothing but tensors and plain containers
-    and loads with ``torch.load(weights_only=True)`` (the reference's ``safe_torch_load``)."""
+    """Python / NumPy / torch generator states (what ``/root/reference/ssi/checkpoint.py:188-197`` saves).  The NumPy Mersenne-Twister
+    key array is stored as a TENSOR, under a key of its own (``numpy_global_tensors``): ``training_state.pt`` then holds nothing but
+    tensors and plain containers and loads with ``torch.load(weights_only=True)``.  The reference's ``numpy_global`` entry is the raw
+    ``np.random.get_state()`` tuple (an ndarray inside), which that restricted loader refuses — the two writers' files are therefore
+    NOT interchangeable ("training_state.pt"); model weights (safetensors) are."""
     kind, keys, pos, has_gauss, cached = np.random.get_state()
     state = {"python": random.getstate(),
-             "numpy_global": (str(kind), torch.from_numpy(np.asarray(keys, dtype=np.int64)), int(pos), int(has_gauss), float(cached)),
+             "numpy_global_tensors": (str(kind), torch.from_numpy(np.asarray(keys, dtype=np.int64)), int(pos), int(has_gauss), float(cached)),
              "torch_cpu": torch.get_rng_state()}
     if torch.cuda.is_available():
         state["torch_cuda"] = torch.cuda.get_rng_state_all()
@@ -49,9 +51,9 @@ def save_rng_states() -> dict[str, Any]:
 def restore_rng_states(state: dict[str, Any]) -> None:
     py = state["python"]
     random.setstate((py[0], tuple(py[1]), py[2]))  # lists -> tuples if a loader relaxed them
-    kind, keys, pos, has_gauss, cached = state["numpy_global"] if "numpy_global" in state else state["numpy"]
-    keys = keys.numpy() if isinstance(keys, torch.Tensor) else np.asarray(keys)
-    np.random.set_state((str(kind), keys.astype(np.uint32), int(pos), int(has_gauss), float(cached)))
+    # "numpy_global" with a tensor inside: files this package wrote before the key was renamed
+    kind, keys, pos, has_gauss, cached = state["numpy_global_tensors"] if "numpy_global_tensors" in state else state["numpy_global"]
+    np.random.set_state((str(kind), keys.numpy().astype(np.uint32), int(pos), int(has_gauss), float(cached)))
     torch.set_rng_state(state["torch_cpu"])
     if "torch_cuda" in state and torch.cuda.is_available():
         torch.cuda.set_rng_state_all(state["torch_cuda"])
@@ -60,7 +62,15 @@ def restore_rng_states(state: dict[str, Any]) -> None:
 def load_training_state(path: str) -> dict[str, Any]:
     """``training_state.pt`` through the restricted unpickler only (tensors, numbers, strings, lists/tuples/dicts): nothing in the
     file is executed (reference: ``safe_torch_load``, ``ssi/checkpoint.py:334``)."""
-    return torch.load(path, map_location="cpu", weights_only=True)
+    import pickle
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        raise RuntimeError(
+            f"{path}: not loadable by the restricted loader (weights_only=True).  It was written by the reference trainer or by an early "
+            "build of this package, whose RNG section holds NumPy arrays (`numpy_global` / `numpy`); such objects are never unpickled "
+            "here.  Resume from a training state written by this package, or restart the optimizer state from the model weights "
+            f"(checkpointer.training_state_checkpoint=null).  Loader message: {e}") from e
 
 
 @torch.no_grad()

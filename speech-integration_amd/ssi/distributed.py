@@ -54,7 +54,7 @@ class GradSync:
         self.flat_grad, self.buckets, self.group = flat_grad, list(buckets), group
         self._pending: list = []
         self._done: set[str] = set()
-        self._deferred = None          # (work, (lo, hi)) of the bucket finish(defer_last=True) left in flight
+        self._deferred = None          # ((work, done event), (lo, hi)) of the bucket finish(defer_last=True) left in flight
         self._last_range = (0, 0)
         self._comm_stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         self.bytes_reduced = 0
@@ -94,7 +94,23 @@ class GradSync:
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append(work)
+        self._pending.append((work, self._record_done(buf.device)))
+
+    def _record_done(self, device):
+        """Event on the communication stream right behind the collective just issued: what the compute stream is made to wait for,
+        in addition to ``work.wait()`` — gloo's wait blocks the host and would hide a missing stream dependency, RCCL's only orders the
+        stream that is current when it is called."""
+        if self._comm_stream is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self._comm_stream)
+        return ev
+
+    def _wait(self, item) -> None:
+        work, done = item
+        work.wait()
+        if done is not None:
+            torch.cuda.current_stream(self.flat_grad.device).wait_event(done)
 
     def finish(self, defer_last: bool = False) -> None:
         """Reduce whatever was not announced and make the compute stream wait for the reductions.  With ``defer_last`` the
@@ -102,17 +118,15 @@ class GradSync:
         left to hide it behind) is left to ``finish_deferred()``: the optimizer updates every other parameter first
         (``HipAdamW.step``) while that reduction is still on the links.  Only for callers that do not read the whole
         gradient in between (no global-norm clipping)."""
-        self._deferred = None
+        self.finish_deferred()  # a bucket a caller left in flight is never dropped
         if self.enabled:
             for name, lo, hi in self.buckets:
                 self.bucket_ready(name, lo, hi)
             if defer_last and len(self._pending) > 1:
                 self._deferred = (self._pending.pop(), self._last_range)
             mark = self._mark()
-            for work in self._pending:
-                work.wait()
-            if self._comm_stream is not None and self._deferred is None:
-                torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._comm_stream)
+            for item in self._pending:  # every bucket but a deferred one: the compute stream waits for its completion event
+                self._wait(item)
             self._mark(mark)
         self._pending.clear()
         self._done.clear()
@@ -124,9 +138,7 @@ class GradSync:
     def finish_deferred(self) -> None:
         if self._deferred is not None:
             mark = self._mark()
-            self._deferred[0].wait()
-            if self._comm_stream is not None:
-                torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._comm_stream)
+            self._wait(self._deferred[0])
             self._mark(mark)
             self._deferred = None
 

@@ -239,6 +239,7 @@ class HipLlamaDecoder(nn.Module):
         self._grads_stale = False
         self._emb_grad_written = False
         self.label_errors: Optional[Tensor] = None        # device count of out-of-range labels seen by the last fused loss
+        self.position_errors: Optional[Tensor] = None     # device count of input_pos entries outside the RoPE table in the last forward
         self.grad_sync = None                             # optional ssi.distributed.GradSync
         self.sync_this_backward = False
 
@@ -328,7 +329,38 @@ class HipLlamaDecoder(nn.Module):
             for p, _, _ in self._param_src:
                 p.grad = None
         self._grads_dirty = False
+        self._emb_grad_written = False  # a head backward whose decoder backward never ran (exception in between) leaves it set
         self.pending_grad_scale = None
+
+    def _window_accumulates(self) -> bool:
+        """Does the backward about to run ADD to the gradient buffer (True) or WRITE it (False: first backward of a window)?
+
+        ``_grads_dirty`` alone is not enough: an optimizer the model does not know (``torch.optim.AdamW`` on the parameter views,
+        INTEGRATION.md level 2) ends a window with ``optimizer.zero_grad(set_to_none=True)``, which drops every ``p.grad`` without telling
+        the model.  Every ``p.grad is None`` therefore opens a new window whatever the flag says — ``torch``'s own meaning of "no
+        gradient yet".  Some ``None`` and some not (a caller cleared a subset): those parameters' slices are zeroed and the backward adds,
+        which is what autograd's accumulation would give."""
+        if self.always_accumulate:
+            return True
+        if not self._grads_dirty:
+            return False
+        dropped = [(p, name, rows) for p, name, rows in self._param_src if p.grad is None]
+        if not dropped:
+            return True
+        if len(dropped) == len(self._param_src):
+            self._grads_dirty, self._grads_stale, self._emb_grad_written = False, True, False
+            self.pending_grad_scale = None
+            return False
+        for p, name, rows in dropped:  # re-attached at once: the decoder backward behind a head backward asks again
+            p.grad = self._view(name, rows, self._flat_grad).zero_()
+        return True
+
+    def _finish_pending_exchange(self) -> None:
+        """A data-parallel bucket left in flight (``GradSync.finish(defer_last=True)``) must have landed before a backward writes the
+        gradient buffer again; ``HipAdamW.step`` normally does this, a caller that skipped the step must not race the reduction."""
+        sync = self.grad_sync
+        if sync is not None and hasattr(sync, "finish_deferred"):
+            sync.finish_deferred()
 
     def activation_bytes(self) -> int:
         return self._arena.bytes()
@@ -371,6 +403,7 @@ class HipLlamaDecoder(nn.Module):
     def _forward_hidden(self, tokens: Tensor, save: bool, input_pos: Optional[Tensor] = None) -> Tensor:
         B, S = tokens.shape
         pos = ds = de = None
+        self.position_errors = None
         if input_pos is not None:
             if input_pos.shape != tokens.shape:
                 raise ValueError("input_pos must have the shape of tokens")
@@ -378,7 +411,9 @@ class HipLlamaDecoder(nn.Module):
                 raise ValueError("input_pos exceeds the RoPE cache")
             # device tensor: no blocking read-back in the step; positions are clamped to the cache instead (the data layer bounds
             # them by tokenizer.max_seq_len <= rope cache, ssi/data/packed.py), so the kernels never index past the table
-            pos, ds, de = ops.doc_ranges(input_pos.to(tokens.device), self._rope.shape[0] - 1)  # one launch (was ~10 torch ops)
+            # and the clamped positions are COUNTED (position_errors): the trainer raises on them from its one read-back per micro-batch
+            self.position_errors = torch.zeros(1, dtype=torch.int32, device=tokens.device)
+            pos, ds, de = ops.doc_ranges(input_pos.to(tokens.device), self._rope.shape[0] - 1, self.position_errors)  # one launch
         T, D, I = B * S, self.embed_dim, self.intermediate_dim
         H, KV, hd, dt, A = self.num_heads, self.num_kv_heads, self.head_dim, self.dtype, self._arena
         if S > self._rope.shape[0]:
@@ -430,7 +465,8 @@ class HipLlamaDecoder(nn.Module):
         H, KV, hd, dt, A = self.num_heads, self.num_kv_heads, self.head_dim, self.dtype, self._arena
         L = self.num_layers
         G = self._flat_grad
-        acc = self._grads_dirty or self.always_accumulate  # False: first backward of the window, every gradient is written, not added
+        acc = self._window_accumulates()  # False: first backward of the window, every gradient is written, not added
+        self._finish_pending_exchange()
         gv = lambda name: self._view(name, None, G)  # noqa: E731
         ws = A.get("ws.rms", (max(ops.rmsnorm_bwd_workspace_bytes(T, D), 16),), torch.uint8)
 
@@ -542,7 +578,8 @@ class HipLlamaDecoder(nn.Module):
     def _head_backward(self, dlogits: Tensor, hn: Tensor, alpha_dev: Optional[Tensor]) -> Tensor:
         """d_hn = alpha * dlogits @ E ;  dE += alpha * dlogits^T @ hn   (dlogits: [T, vocab_pad], pad columns zero)."""
         T, D = hn.shape
-        acc = self._grads_dirty or self.always_accumulate
+        acc = self._window_accumulates()
+        self._finish_pending_exchange()
         d_hn = self._arena.get("d_hn", (T, D), self.dtype)
         self._ensure_transposed()
         if self._has_t("emb"):

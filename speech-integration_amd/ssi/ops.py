@@ -103,13 +103,16 @@ def _doc_ptrs(doc_start: Optional[Tensor], doc_end: Optional[Tensor], rows: int)
     return ptr(doc_start), ptr(doc_end)
 
 
-def doc_ranges(input_pos: Tensor, max_pos: int) -> tuple[Tensor, Tensor, Tensor]:
-    """Packed rows: int32 [B*S] (positions clamped to max_pos, doc_start, doc_end) from input_pos [B, S] in one launch."""
+def doc_ranges(input_pos: Tensor, max_pos: int, n_clamped: Tensor | None = None) -> tuple[Tensor, Tensor, Tensor]:
+    """Packed rows: int32 [B*S] (positions clamped to max_pos, doc_start, doc_end) from input_pos [B, S] in one launch.  ``n_clamped``
+    (int32 [1], zeroed by the caller) receives the number of positions that had to be clamped."""
     assert input_pos.dim() == 2 and input_pos.dtype == torch.int64
+    assert n_clamped is None or (n_clamped.dtype == torch.int32 and n_clamped.numel() == 1)
     ip = input_pos.contiguous()
     B, S = ip.shape
     out = torch.empty(3, B * S, dtype=torch.int32, device=ip.device)
-    check(_lib.load().ssi_doc_ranges(ptr(ip), B, S, int(max_pos), ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()), "ssi_doc_ranges")
+    check(_lib.load().ssi_doc_ranges(ptr(ip), B, S, int(max_pos), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(n_clamped), stream_ptr()),
+          "ssi_doc_ranges")
     return out[0], out[1], out[2]
 
 

@@ -9,6 +9,7 @@ next accumulation window overwrites it (``HipLlamaDecoder`` gradient-buffer prot
 
 from __future__ import annotations
 
+import weakref
 from typing import Any, Iterable
 
 import torch
@@ -32,6 +33,7 @@ class HipAdamW(torch.optim.Optimizer):
         if len(self.param_groups) != 1:
             raise NotImplementedError("one param group expected (the reference passes model.parameters())")
         self.model = model
+        model._hip_optimizer = weakref.ref(self)  # scale_grads / clip_grad_norm_ may defer their factor only while THIS optimizer consumes it
         self._exp_avg = torch.zeros_like(model._flat)
         self._exp_avg_sq = torch.zeros_like(model._flat)
         self._step_count = 0
@@ -54,6 +56,14 @@ class HipAdamW(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         m = self.model
+        if all(p.grad is None for p, _, _ in m._param_src):
+            # no backward since the last zero_grad (skipped or failed micro-batches): torch.optim.AdamW skips parameters without a
+            # gradient; the never-zeroed buffer still holds the LAST window's gradients, which must not be applied a second time
+            sync = getattr(m, "grad_sync", None)
+            if sync is not None and hasattr(sync, "finish_deferred"):
+                sync.finish_deferred()
+            m.pending_grad_scale = None
+            return loss
         self._step_count += 1
 
         def update(lo: int, hi: int) -> None:
@@ -135,12 +145,26 @@ def setup_optimizer(cfg, model, optimizer_state_dict: dict[str, Any] | None = No
     return optimizer
 
 
+def _hip_optimizer_of(model):
+    """The live :class:`HipAdamW` built on ``model`` (it registers itself), or None when the caller brought its own optimizer."""
+    ref = getattr(model, "_hip_optimizer", None)
+    return ref() if ref is not None else None
+
+
 def scale_grads(model, scaler: Tensor | float) -> None:
     """torchtune ``training.scale_grads`` (``trainer.py:404``): ``p.grad *= scaler`` for every parameter.  On the HIP
     decoder the multiplication is deferred: it is folded into the optimizer kernel (and into the clip norm), saving a
-    full read+write pass over the 2.5 GB gradient buffer."""
+    full read+write pass over the 2.5 GB gradient buffer.  Without a :class:`HipAdamW` on the model (INTEGRATION.md level 2: the
+    caller's own ``torch.optim`` optimizer on the parameter views) nothing would ever consume a deferred factor, so the
+    multiplication happens at once, in place, by the HIP ``scale`` kernel."""
     if hasattr(model, "_flat_grad"):
         s = torch.as_tensor(scaler, dtype=torch.float32).reshape(1).to(model._flat_grad.device, non_blocking=True)
+        if _hip_optimizer_of(model) is None:  # a foreign optimizer reads p.grad itself: multiply now (one pass over the flat buffer)
+            sync = getattr(model, "grad_sync", None)
+            if sync is not None and hasattr(sync, "finish_deferred"):
+                sync.finish_deferred()
+            ops.scale_(model._flat_grad, scale_dev=s)
+            return
         model.pending_grad_scale = s if model.pending_grad_scale is None else model.pending_grad_scale * s
         return
     for p in model.parameters():
@@ -162,5 +186,9 @@ def clip_grad_norm_(model, max_norm: float) -> Tensor:
     scale = model.pending_grad_scale if model.pending_grad_scale is not None else torch.ones_like(out)
     total_norm = out.sqrt() * scale.abs()
     coef = torch.clamp(float(max_norm) / (total_norm + 1e-6), max=1.0)
-    model.pending_grad_scale = scale * coef
+    if _hip_optimizer_of(model) is None:  # nobody will consume a deferred factor (scale is 1 here: scale_grads was eager too)
+        ops.scale_(model._flat_grad, scale_dev=(scale * coef).reshape(1).contiguous())
+        model.pending_grad_scale = None
+    else:
+        model.pending_grad_scale = scale * coef
     return total_norm.reshape(())

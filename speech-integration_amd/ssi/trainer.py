@@ -150,6 +150,7 @@ class Trainer:
         self._grad_norm: float | None = None
         self._loss_log: list[float] | None = None
         self._type_counts_window: defaultdict[str, int] = defaultdict(int)  # this rank's counts since the last optimizer step
+        self._bad_inputs_window: defaultdict[str, int] = defaultdict(int)   # ids / positions the kernels had to refuse, same window
         # data parallel
         self.grad_sync: GradSync | None = None
         self._resume_state: dict[str, Any] | None = None
@@ -347,18 +348,23 @@ class Trainer:
         loss_batch = compute_loss(batch, self.model, self.loss_fn) * n_valid  # mean over SHIFTED x UNSHIFTED count
         loss_batch.backward()
         if on_gpu:
-            bad_labels = getattr(self.model, "label_errors", None)
-            bad_labels = bad_labels.detach().to(torch.float64).reshape(1) if bad_labels is not None else torch.zeros(1, dtype=torch.float64, device=tokens.device)
-            host = torch.cat((counts_dev.to(torch.float64), loss_batch.detach().to(torch.float64).reshape(1), bad_labels)).tolist()
+            zero = torch.zeros(1, dtype=torch.float64, device=tokens.device)
+            errs = [getattr(self.model, "label_errors", None), getattr(self.model, "position_errors", None)]
+            errs = [zero if e is None else e.detach().to(torch.float64).reshape(1) for e in errs]
+            host = torch.cat((counts_dev.to(torch.float64), loss_batch.detach().to(torch.float64).reshape(1), *errs)).tolist()
             names = list(self.token_type_ranges) + ["total"]
             counts_host = {tt: int(c) for tt, c in zip(names, host)}
-            num_tokens_iter, loss_value = int(host[len(names)]), float(host[-2])
+            num_tokens_iter, loss_value = int(host[len(names)]), float(host[-3])
             # ids outside the vocabulary: torch's embedding / cross_entropy would device-assert (the HIP kernels write zeros and count);
-            # the token-type ranges partition [0, V), so a token outside them shows up as a short sum — both read from this one copy
-            if int(host[-1]) != 0:
-                raise IndexError(f"{int(host[-1])} label(s) outside [0, vocab_size) in this micro-batch")
-            if sum(counts_host[tt] for tt in self.token_type_ranges) != tokens.numel():
-                raise IndexError("token id(s) outside [0, vocab_size) in this micro-batch")
+            # the token-type ranges partition [0, V), so a token outside them shows up as a short sum; positions beyond the RoPE table are
+            # clamped by the kernel and counted — all read from this one copy
+            bad = {"labels outside [0, vocab_size)": int(host[-2]),
+                   "token ids outside [0, vocab_size)": tokens.numel() - sum(counts_host[tt] for tt in self.token_type_ranges),
+                   "input_pos entries outside the RoPE table": int(host[-1])}
+            for what, n_bad in bad.items():
+                self._bad_inputs_window[what] += n_bad
+            if self.grad_sync is None:  # alone: fail here; data parallel: at the window's scalar all-reduce, on EVERY rank (a rank that
+                self._raise_on_bad_inputs(self._bad_inputs_window)  # raised alone would leave the others blocked in their collectives)
         else:
             num_tokens_iter, loss_value = int(n_valid.item()), float(loss_batch.item())
         for tt, c in counts_host.items():
@@ -367,19 +373,30 @@ class Trainer:
         self.num_tokens_step += num_tokens_iter
         self.loss_running += loss_value
 
+    @staticmethod
+    def _raise_on_bad_inputs(bad: dict[str, int], anywhere: int | None = None) -> None:
+        mine = {what: n for what, n in bad.items() if n}
+        if mine or anywhere:
+            here = "; ".join(f"{n} {what}" for what, n in mine.items()) or "none on this rank"
+            raise IndexError(f"invalid ids in this accumulation window: {here}" + (f" ({anywhere} over all ranks)" if anywhere else ""))
+
     def _optimizer_step(self, epoch: int, iter_idx: int) -> None:
         """Accumulation boundary (``trainer.py:397-424``): [all-reduce] -> scale -> clip -> AdamW -> LR -> counters."""
         if self.grad_sync is not None:
             # one small collective: token count, running loss and the window's token-type counts (tokens_total is global, so the
             # per-type totals must be too: every rank adds what the OTHER ranks saw in this window)
             kinds = sorted(self._type_counts_window)
-            summed = all_reduce_scalars([self.num_tokens_step, self.loss_running, *(self._type_counts_window[k] for k in kinds)],
-                                        self.device, group=self.grad_sync.scalar_group)
+            summed = all_reduce_scalars([self.num_tokens_step, self.loss_running, float(sum(self._bad_inputs_window.values())),
+                                         *(self._type_counts_window[k] for k in kinds)], self.device, group=self.grad_sync.scalar_group)
             self.num_tokens_step, self.loss_running = int(round(summed[0])), float(summed[1])
-            for k, v in zip(kinds, summed[2:]):
+            for k, v in zip(kinds, summed[3:]):
                 self.token_type_counts_total[k] += int(round(v)) - self._type_counts_window[k]
             self.grad_sync.finish(defer_last=self.cfg.clip_grad_norm is None)  # the embedding bucket lands under the AdamW of the rest
+            if summed[2] > 0:  # every rank sees the same sum, so every rank raises (after its reductions have drained)
+                self.grad_sync.finish_deferred()
+                self._raise_on_bad_inputs(self._bad_inputs_window, anywhere=int(round(summed[2])))
         self._type_counts_window.clear()
+        self._bad_inputs_window.clear()
         if self.num_tokens_step == 0:
             LOGGER.warning("No non-ignored tokens in accumulation window; skipping optimizer step.")
             self.optimizer.zero_grad(set_to_none=True)

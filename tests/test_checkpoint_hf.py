@@ -124,8 +124,9 @@ def test_missing_weights_raise_unless_random_init_is_asked_for(tmp_path):
 
 
 def test_training_state_round_trips_through_the_restricted_loader(tmp_path):
-    """training_state.pt holds tensors and plain containers only: it loads with weights_only=True, carries the reference's RNG keys
-    (python, numpy_global, torch_cpu) and restores the three generators exactly."""
+    """training_state.pt holds tensors and plain containers only: it loads with weights_only=True, carries the three generator states
+    (python, torch_cpu, and NumPy's as tensors under a key of its own) and restores them exactly.  A file whose RNG section holds a
+    raw NumPy array (what the reference writes under ``numpy_global``) is refused with a message that says so."""
     import random
 
     import numpy as np
@@ -140,10 +141,22 @@ def test_training_state_round_trips_through_the_restricted_loader(tmp_path):
                                   cumulative_metrics={"tokens_train_total": 10, "token_type_counts": {"text": 3}, "wall_clock_seconds": 1.5})
     want = (random.random(), np.random.standard_normal(2).tolist(), np.random.randint(0, 100), torch.rand(2))
     state = torch.load(path, map_location="cpu", weights_only=True)
-    assert set(state["rng_state"]) >= {"python", "numpy_global", "torch_cpu"} and state["global_step"] == 4
+    assert set(state["rng_state"]) >= {"python", "numpy_global_tensors", "torch_cpu"} and state["global_step"] == 4
     random.seed(0), np.random.seed(0), torch.manual_seed(0)
     restore_rng_states(state["rng_state"])
     got = (random.random(), np.random.standard_normal(2).tolist(), np.random.randint(0, 100), torch.rand(2))
     assert got[:3] == want[:3] and torch.equal(got[3], want[3])
     resumed = TuneCheckpointer(checkpoint_dir=None, output_dir=str(tmp_path), allow_random_init=True, training_state_checkpoint=path).load_checkpoint()
     assert resumed["consumed_samples"] == 8 and resumed["cumulative_metrics"]["token_type_counts"] == {"text": 3}
+    # the previous key (round-2 files: tensor form under the reference's name) still restores
+    legacy = dict(state["rng_state"])
+    legacy["numpy_global"] = legacy.pop("numpy_global_tensors")
+    random.seed(0), np.random.seed(0), torch.manual_seed(0)
+    restore_rng_states(legacy)
+    assert (random.random(), np.random.standard_normal(2).tolist(), np.random.randint(0, 100)) == want[:3]
+    # a foreign writer's file: ndarray inside -> refused by the restricted loader, with a clear message
+    from ssi.checkpoint import load_training_state
+    foreign = tmp_path / "foreign_training_state.pt"
+    torch.save({"rng_state": {"numpy_global": np.random.get_state()}}, foreign)
+    with pytest.raises(RuntimeError, match="restricted loader"):
+        load_training_state(str(foreign))

@@ -16,8 +16,9 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_two_rank_rccl_step_equals_single_process_step(tmp_path):
-    if torch.cuda.device_count() < 2:   # device_count() does not initialise the GPU
+def test_rccl_step_on_every_gpu_equals_single_process_step(tmp_path):
+    n_ranks = min(torch.cuda.device_count(), 8)  # every GPU of the node: the first multi-GPU box exercises the 8-rank communicator
+    if n_ranks < 2:   # device_count() does not initialise the GPU
         pytest.skip("needs >= 2 GPUs")
     if torch.cuda.is_initialized():
         pytest.skip("this process already holds the GPU: ranks must be started from a process that has not touched it")
@@ -28,9 +29,9 @@ def test_two_rank_rccl_step_equals_single_process_step(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("SSI_DIST_BACKEND", None)
     env.pop("SSI_LOCAL_DEVICE", None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "workers", "dp_step_worker.py"), "--out", str(out)]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stdout[-4000:] + proc.stderr[-4000:]
     verdict = json.loads(out.read_text())
-    assert verdict["backend"] == "nccl" and verdict["world"] == 2 and verdict["ok_all_ranks"], verdict
+    assert verdict["backend"] == "nccl" and verdict["world"] == n_ranks and verdict["ok_all_ranks"], verdict
