@@ -136,19 +136,20 @@ class GemmTimer:
 
 
 def pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_traffic.json, written by tools/pmc_traffic.py
-    from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None when no pass covers the kernel."""
+    """(HBM bytes per launch of `kernel`, the file it was read from) from the committed PMC passes (profiles/*_traffic.json, written by
+    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command) — NOT measured by this run;
+    (None, None) when no pass covers the kernel."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
-    best = None
+    best, src = None, None
     for f in sorted(glob.glob(os.path.join(here, "profiles", "*_traffic.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("bench_kernel") == kernel:
-            best = d.get("traffic_bytes_per_launch")
-    return best
+        if d.get("bench_kernel") == kernel and d.get("traffic_bytes_per_launch") is not None:
+            best, src = d.get("traffic_bytes_per_launch"), os.path.join("profiles", os.path.basename(f))
+    return best, src
 
 
 def usable_cores() -> int:
@@ -246,6 +247,59 @@ def self_launch(n: int) -> int:
     return proc.returncode
 
 
+def through_trainer(args) -> int:
+    """Secondary measurement (NOT the headline line): the same workload through the drop-in entry point — what ``scripts/train_sft.py``
+    does (``/root/reference/scripts/train_sft.py:9-15``): compose ``conf/sft.yaml``, ``Trainer(cfg).setup(); .train()`` — with the device
+    prefetcher, per-step logging and the reference's bookkeeping in the loop, at ``gradient_accumulation_steps`` 1 and the reference's
+    default 4.  Reported: the trainer's own ``tokens_per_second_per_gpu`` (``/root/reference/ssi/trainer.py:462-467``: non-ignored label
+    tokens of the window / wall time between optimizer steps) and the positions/s it corresponds to (B x S x ga / duration_step), both as the
+    mean over the steps after the warm-up, next to the step time."""
+    import shutil
+    import tempfile
+    from ssi.config import compose
+    from ssi.train_utils import resolve_n_dsus
+    from ssi.trainer import Trainer
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    runs = {}
+    for ga in (1, 4):
+        tmp = tempfile.mkdtemp(prefix="ssi_through_trainer_")
+        steps = args.warmup + args.steps
+        cfg = compose(os.path.join(PKG, "conf"), "sft", [
+            "data=sft/mls-hubert_large_ll60k-layer_22", f"dtype={args.dtype}", f"max_steps={steps}", f"gradient_accumulation_steps={ga}",
+            f"tokenizer.max_seq_len={args.seq}", f"data.train.dataset.n_samples={steps * ga * args.batch}", "data.dev.dataset.n_samples=8",
+            f"data.train.dataloader.batch_size={args.batch}", "eval_steps=1000000000", "save_steps=1000000000", f"output_dir={tmp}",
+            f"checkpointer.output_dir={tmp}/ckpt", f"checkpointer.checkpoint_dir={tmp}/none", "checkpointer.allow_random_init=true",
+            f"speech.n_dsus={args.n_dsus}"])
+        resolve_n_dsus(cfg)
+        t = Trainer(cfg)
+        t.setup()
+        assert t.model.num_layers == 16 and t.model.vocab_size == 128_256 + args.n_dsus + 2
+        t0 = time.perf_counter()
+        t.train()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        rec = t.wandb_logger.records[args.warmup:]
+        assert len(rec) == args.steps and t.global_step == steps
+        dur = [r["duration_step"] for r in rec]
+        runs[f"grad_accum_{ga}"] = {
+            "tokens_per_second_per_gpu": sum(r["tokens_per_second_per_gpu"] for r in rec) / len(rec),
+            "positions_per_second": sum(ga * args.batch * args.seq / d for d in dur) / len(dur),
+            "ms_per_optimizer_step": 1e3 * sum(dur) / len(dur), "ms_per_micro_batch": 1e3 * sum(dur) / len(dur) / ga,
+            "steps": len(rec), "warmup": args.warmup, "train_wall_s": wall, "last_loss": rec[-1]["loss"]}
+        t.cleanup()
+        del t
+        torch.cuda.empty_cache()
+        shutil.rmtree(tmp, ignore_errors=True)
+    print(json.dumps({"metric": "train_tokens_per_sec", "mode": "through_trainer", "unit": "tokens/s", "n_gpus": 1, "dtype": args.dtype,
+                      "data": "synthetic", "higher_is_better": True,
+                      "config": {"workload": f"scripts/train_sft.py path: compose(conf/sft.yaml) -> Trainer.setup() -> Trainer.train(); Llama-3.2-1B "
+                                             f"+{args.n_dsus} DSUs, seq_len={args.seq}, batch={args.batch}, prefetcher on, log_interval=1, 16 layers, "
+                                             "random-init weights, MLS-shaped synthetic DSU sequences"},
+                      "value": runs["grad_accum_1"]["positions_per_second"], "runs": runs}), flush=True)
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,6 +316,9 @@ def main() -> int:
     ap.add_argument("--padded", action="store_true",
                     help="secondary workload (SURVEY.md §8d): sequence lengths ~U(0.4 S, S), right-padded to the batch maximum; "
                          "tokens/s then counts NON-PAD tokens.  Not the headline line.")
+    ap.add_argument("--through-trainer", action="store_true",
+                    help="secondary line: the workload through Trainer.setup()/train() (the scripts/train_sft.py path) at grad-accum 1 and 4; "
+                         "one GPU.  Not the headline line.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timing", action="store_true")
     args = ap.parse_args()
@@ -272,6 +329,8 @@ def main() -> int:
     if world != args.gpus:
         print(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
         return 2
+    if args.through_trainer:
+        return through_trainer(args)
     local = int(os.environ.get("SSI_LOCAL_DEVICE", local))  # rehearsal hook: several ranks on one GPU (with SSI_DIST_BACKEND=gloo)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
@@ -398,10 +457,11 @@ def main() -> int:
             sym.update({(l, pv, "batched"): f"gemm_nt4dma_kernel<{lay[l]},0,{pv},false,true>" for l in lay for pv in (0, 1)})
             dom = max(per, key=lambda k: per[k][1])
             n, ms, fl = per[dom]
+            traffic, traffic_src = pmc_traffic(sym.get(dom, ""))
             out["roofline"] = {
                 "bound": "mfma", "kernel": sym.get(dom, f"gemm_mfma_kernel layout={dom[0]}"),
                 "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(sym.get(dom, "")),
+                "frac": fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 "launches": n, "avg_launch_ms": ms / n, "flop_per_launch_avg": fl / n,
                 "share_of_step_time": ms / (1e3 * elapsed),
                 "other_gemm_kernels": {sym.get(k, str(k)): {"launches": v[0], "avg_ms": v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12}

@@ -16,6 +16,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _usable_cores() -> int:
+    """Cores this process may really use (affinity mask and cgroup quota): the GPU box shows 128 logical CPUs to a 16-core share, and
+    the CPU oracle on 128 threads runs at half the speed it reaches on 16."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    import torch
+    torch.set_num_threads(min(_usable_cores(), 32))
+    yield
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
 

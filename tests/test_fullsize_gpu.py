@@ -17,6 +17,11 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+# Per-parameter relative gradient error of the bf16 model vs the fp32 oracle.  The yardstick test below shows where it comes from: the
+# oracle itself run with bf16 parameters (the reference's arithmetic on a bf16 model) is 4.77e-2 from its fp32 self on its worst
+# parameter (layers.15.attn.k_proj.weight), the HIP model 4.69e-2 on the same one; worst HIP / oracle-bf16 ratio over the 146 parameters
+# 1.04, median 0.99 (config P; at configs C / E / A the worst HIP errors are 4.41e-2 / 4.39e-2 / 4.56e-2).  Round 2 had 6e-2 here.
+TOL_GRAD_BF16 = 5.5e-2
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -100,7 +105,7 @@ def test_full_size_model_matches_the_cpu_oracle(dtype_name, n_dsus):
     loss = compute_loss(batch, model, CEWithChunkedOutputLoss())
     loss.backward()
     rel = abs(loss.item() - R["loss"]) / abs(R["loss"])
-    tol_loss, tol_logit, tol_grad = (1e-4, 1e-3, 2e-3) if dtype_name == "fp32" else (1e-2, 5e-2, 6e-2)
+    tol_loss, tol_logit, tol_grad = (1e-4, 1e-3, 2e-3) if dtype_name == "fp32" else (1e-2, 5e-2, TOL_GRAD_BF16)
     print(f"[full-size {dtype_name}] loss {loss.item():.6f} vs oracle {R['loss']:.6f}: rel {rel:.2e} (tolerance {tol_loss})")
     assert rel <= tol_loss
     worst, worst_key = 0.0, None
@@ -123,6 +128,110 @@ def test_full_size_model_matches_the_cpu_oracle(dtype_name, n_dsus):
     print(f"[full-size {dtype_name}] logits max-abs error {err:.3e} vs max |logit| {scale:.3f} (tolerance {tol_logit} x)")
     assert err <= tol_logit * scale
     assert int(torch.argmax(got, -1).eq(torch.argmax(R["logit_rows"], -1)).sum()) >= (8 if dtype_name == "fp32" else 6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 1b. The whole 1B model against the CPU oracle at the OTHER BASELINE.json shapes: config C (S = 4096), config E (packed rows of 8192,
+#     V = 130 306, the oracle fed torchtune's dense block-causal mask) and the headline batch itself, config A (B = 8, S = 2048).
+#     What config P's 512-token rows cannot reach: RoPE positions > 2047, the 32- and 64-key-group attention work maps inside the model,
+#     M = 8192 / 16 384-row tile walks of every GEMM, the 16-round head weight gradient, per-document positions at full width.
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_at(n_dsus, batch, rope_len, dtype=torch.float32):
+    """Loss and every gradient of the CPU oracle (``oracle/llama_oracle.py``, restating ssi/loss.py:7-22) on ``batch``; the weights are
+    ``_seeded_full_state_dict(params, 2024)`` (bf16-representable), cast to ``dtype`` for the rounding yardstick."""
+    import time
+    from oracle.llama_oracle import OracleCEWithChunkedOutputLoss, OracleLlama
+    from oracle.llama_oracle import compute_loss as oracle_loss
+    from ssi.data import packed_block_causal_mask
+    cfg = _full_config(n_dsus)
+    params = cfg.parameters
+    sd = _seeded_full_state_dict(params, 2024)
+    with torch.device("meta"):
+        ref = OracleLlama(**params, rope_cache_len=rope_len)
+    rope = ref.rope.clone()
+    ref = ref.to_empty(device="cpu")
+    ref.rope = rope
+    ref.load_state_dict(sd)
+    if dtype != torch.float32:
+        for p in ref.parameters():   # parameters only: the RoPE table stays fp32 (torchtune calls .float() on it)
+            p.data = p.data.to(dtype)
+    ref.set_num_output_chunks(8)
+    ref_batch = {k: v for k, v in batch.items() if k in ("tokens", "labels", "input_pos")}
+    if "seq_lens" in batch:
+        ref_batch["mask"] = packed_block_causal_mask(batch["seq_lens"])
+    t0 = time.time()
+    loss = oracle_loss(ref_batch, ref, OracleCEWithChunkedOutputLoss())
+    loss.backward()
+    grads = {k: p.grad.float().clone() for k, p in ref.named_parameters()}
+    print(f"[oracle {dtype}] {batch['tokens'].numel()} tokens: forward + backward {time.time() - t0:.1f} s on {torch.get_num_threads()} threads")
+    out = dict(cfg=cfg, params=params, sd=sd, loss=float(loss.detach()), grads=grads)
+    del ref
+    return out
+
+
+def _hip_at(R, batch, rope_len):
+    from ssi.loss import CEWithChunkedOutputLoss, compute_loss
+    from ssi.model import HipLlamaDecoder
+    model = HipLlamaDecoder(**R["params"], dtype=torch.bfloat16, device=DEV, rope_cache_len=rope_len)
+    model.load_state_dict(R["sd"])
+    model.set_num_output_chunks(8)
+    assert model._mfma_shapes()
+    model.train()
+    dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    loss = compute_loss(dbatch, model, CEWithChunkedOutputLoss())
+    loss.backward()
+    grads = {k: p.grad.float().cpu() for k, p in model.named_parameters()}
+    return float(loss.item()), grads
+
+
+def _grad_errors(got, want):
+    return {k: float((got[k] - want[k]).norm() / want[k].norm()) for k in want}
+
+
+@pytest.mark.parametrize("config,n_dsus,B,S,packed", [("C", 5000, 1, 4096, False), ("E", 2048, 1, 8192, True), ("A", 5000, 8, 2048, False)],
+                         ids=["config-C-S4096", "config-E-packed-S8192-V130306", "config-A-B8-S2048"])
+def test_full_size_model_matches_the_cpu_oracle_at_the_baseline_shapes(config, n_dsus, B, S, packed):
+    """bf16 HIP model (every MFMA kernel of the step) vs the fp32 CPU oracle from the same bf16-representable weights: loss within 1e-2
+    (north star 1e-3 is the fp32 bar; observed is printed), every one of the 146 gradients within the bf16 tolerance of config P."""
+    from ssi.data import synthetic_batch, synthetic_packed_batch
+    batch = synthetic_packed_batch(B, S, n_dsus, seed=42_831) if packed else synthetic_batch(B, S, n_dsus, seed=42_831)
+    if packed:
+        assert int((batch["input_pos"] == 0).sum()) >= 8 and int(batch["input_pos"].max()) < S
+    R = _oracle_at(n_dsus, batch, S)
+    assert R["params"]["vocab_size"] == {5000: 133_258, 2048: 130_306}[n_dsus]
+    loss, grads = _hip_at(R, batch, S)
+    rel = abs(loss - R["loss"]) / abs(R["loss"])
+    errs = _grad_errors(grads, R["grads"])
+    worst = max(errs, key=errs.get)
+    named = {k: errs[k] for k in ("tok_embeddings.weight", "layers.0.attn.q_proj.weight", "layers.7.attn.k_proj.weight", "layers.15.mlp.w2.weight", "norm.scale")}
+    print(f"[config {config}: B={B} S={S} packed={packed} V={R['params']['vocab_size']}] loss {loss:.6f} vs oracle {R['loss']:.6f}: rel {rel:.2e}; "
+          f"worst gradient error {errs[worst]:.2e} ({worst}); " + ", ".join(f"{k} {v:.2e}" for k, v in named.items()))
+    assert rel <= 1e-2
+    for k, e in errs.items():
+        assert e <= TOL_GRAD_BF16, f"{k}: relative gradient error {e}"
+        nrm = float(grads[k].norm() / R["grads"][k].norm())
+        assert abs(nrm - 1.0) <= TOL_GRAD_BF16, f"{k}: gradient norm ratio {nrm}"
+
+
+def test_bf16_gradient_error_is_the_reference_arithmetics_own_rounding():
+    """Yardstick for the bf16 tolerance: the SAME oracle run once more with bf16 parameters on the CPU (what the reference computes on a
+    bf16 model: bf16 GEMMs with fp32 accumulation, fp32 norm / RoPE / softmax / CE islands) against the fp32 oracle, per parameter, next to
+    the HIP model's error against the fp32 oracle — config P's batch (B = 2, S = 512), full 1B model.  The HIP path may not be further from
+    fp32 than 1.5 x the reference arithmetic's own bf16 rounding."""
+    from ssi.data import synthetic_batch
+    batch = synthetic_batch(2, 512, 5000, seed=42_831)
+    R = _oracle_at(5000, batch, 512)
+    Rb = _oracle_at(5000, batch, 512, dtype=torch.bfloat16)
+    loss, grads = _hip_at(R, batch, 512)
+    e_hip, e_ref = _grad_errors(grads, R["grads"]), _grad_errors(Rb["grads"], R["grads"])
+    ratio = {k: e_hip[k] / max(e_ref[k], 1e-12) for k in e_hip}
+    worst_hip, worst_ref, worst_ratio = max(e_hip, key=e_hip.get), max(e_ref, key=e_ref.get), max(ratio, key=ratio.get)
+    print(f"[bf16 yardstick] loss: HIP rel {abs(loss - R['loss']) / R['loss']:.2e}, oracle-bf16 rel {abs(Rb['loss'] - R['loss']) / R['loss']:.2e}")
+    print(f"[bf16 yardstick] worst HIP gradient error {e_hip[worst_hip]:.2e} ({worst_hip}; oracle-bf16 there {e_ref[worst_hip]:.2e}); "
+          f"worst oracle-bf16 error {e_ref[worst_ref]:.2e} ({worst_ref}; HIP there {e_hip[worst_ref]:.2e}); "
+          f"worst ratio HIP / oracle-bf16 {ratio[worst_ratio]:.2f} ({worst_ratio}); median ratio {sorted(ratio.values())[len(ratio) // 2]:.2f}")
+    for k in e_hip:
+        assert e_hip[k] <= 1.5 * e_ref[k] + 1e-3, f"{k}: HIP {e_hip[k]:.3e} vs the reference arithmetic in bf16 {e_ref[k]:.3e}"
 
 
 # ---------------------------------------------------------------------------------------------------------------------
