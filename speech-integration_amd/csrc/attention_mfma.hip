@@ -61,6 +61,35 @@ __device__ __forceinline__ void block_to_work(int n_blocks, int n_pairs, int& ra
 
 __device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// -DATTN_TRACE (debug build, tools/attn_trace.py): every workgroup leaves its start, the start and end of its tile loop and its end on the
+// 100 MHz constant clock, where it ran (XCC, SE, CU) and its work (tiles / steps) in a device-side table: the occupancy timeline of a launch —
+// per-workgroup cost against its tile count, idle slots, the tail.  Never part of the product build (the extra export would also fail
+// tests/test_abi.py).
+#ifdef ATTN_TRACE
+constexpr int TRACE_MAX = 8192;
+__device__ unsigned long long g_attn_trace[3][TRACE_MAX][6];
+#define TRACE_BEGIN() const unsigned long long tr_t0_ = __builtin_amdgcn_s_memrealtime(); unsigned long long tr_ta_ = 0, tr_tb_ = 0
+#define TRACE_LOOP_BEGIN() tr_ta_ = __builtin_amdgcn_s_memrealtime()   /* prologue issued (loads in flight), tile loop starts */
+#define TRACE_LOOP_END() tr_tb_ = __builtin_amdgcn_s_memrealtime()     /* tile loop done, epilogue starts */
+#define TRACE_END(k, work)                                                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < TRACE_MAX) {                                                                             \
+        unsigned hw_, xcc_;                                                                                                       \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                                        \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                                      \
+        g_attn_trace[k][blockIdx.x][0] = tr_t0_;                                                                                  \
+        g_attn_trace[k][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();                                                        \
+        g_attn_trace[k][blockIdx.x][2] = ((unsigned long long)xcc_ << 32) | hw_;                                                  \
+        g_attn_trace[k][blockIdx.x][3] = (unsigned long long)(work);                                                              \
+        g_attn_trace[k][blockIdx.x][4] = tr_ta_;                                                                                  \
+        g_attn_trace[k][blockIdx.x][5] = tr_tb_;                                                                                  \
+    }
+#else
+#define TRACE_BEGIN()
+#define TRACE_LOOP_BEGIN()
+#define TRACE_LOOP_END()
+#define TRACE_END(k, work)
+#endif
+
 constexpr int HD = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float RESCALE_TAU = 5.545177444479562f;  // 8 ln 2
@@ -204,6 +233,7 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_fwd_kernel(co
                                                        float* __restrict__ lse, const int32_t* __restrict__ doc_start, int S, int H,
                                                        int KV) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 2 * 8192];  // ring of 3 x [K | V][64][64] bf16
+    TRACE_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep = H / KV, qpw = ANW / rep;
     const int nqb = S / (32 * qpw);
@@ -335,11 +365,13 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_fwd_kernel(co
             }
         }
     };
+    TRACE_LOOP_BEGIN();
     for (int t = t_first; t < nt; t += 3) {
         tile_step(t, std::integral_constant<int, 0>{});
         if (t + 1 < nt) tile_step(t + 1, std::integral_constant<int, 1>{});
         if (t + 2 < nt) tile_step(t + 2, std::integral_constant<int, 2>{});
     }
+    TRACE_LOOP_END();
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.f / ltot;
     bf16_t* orow = out + (row0 + qg) * ((int64_t)H * HD) + (int64_t)head * HD;
@@ -353,6 +385,7 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_fwd_kernel(co
             *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * g + 4 * h) = v;
         }
     if (h == 0) lse[((int64_t)b * H + head) * S + qg] = m + logf(ltot);
+    TRACE_END(0, nt - t_first);
 }
 
 
@@ -365,6 +398,7 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_bwd_dq_kernel
                                                           const int32_t* __restrict__ doc_start, const float* __restrict__ rope,
                                                           const int32_t* __restrict__ positions, int S, int H, int KV) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 2 * 8192];  // ring of 3 x [K | V][64][64] bf16
+    TRACE_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep = H / KV, qpw = ANW / rep;
     const int nqb = S / (32 * qpw);
@@ -507,11 +541,13 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_bwd_dq_kernel
             QSTAMP(5)  // conversions + 8 dQ MFMAs issued
         }
     };
+    TRACE_LOOP_BEGIN();
     for (int t = t_first; t < nt; t += 3) {
         tile_step(t, std::integral_constant<int, 0>{});
         if (t + 1 < nt) tile_step(t + 1, std::integral_constant<int, 1>{});
         if (t + 2 < nt) tile_step(t + 2, std::integral_constant<int, 2>{});
     }
+    TRACE_LOOP_END();
     bf16_t* drow = dqkv + (row0 + qg) * ld + (int64_t)head * HD;
 #ifdef DQ_STAMP
     unsigned long long qs_total = __builtin_readcyclecounter() - qs_begin;
@@ -540,6 +576,7 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_bwd_dq_kernel
         }
     }
 #endif
+    TRACE_END(1, nt - t_first);
 }
 
 // =====================================================================================================================
@@ -560,6 +597,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
     constexpr int SB = 8192 + 256;
     constexpr int RING = DKV_RING;
     __shared__ __attribute__((aligned(16))) char smem[RING * SB];
+    TRACE_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep = H / KV;
     const int ngrp = S / 128;
@@ -734,6 +772,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
     for (int i = 0; i < RING - 2; ++i)
         if (i < n_steps) issue(i);
     static_assert(RING % 2 == 0 && RING >= 4 && RING <= 10, "the barrier cadence (one per two steps) needs an even ring");
+    TRACE_LOOP_BEGIN();
     for (int step = 0; step < n_steps; step += RING) {
         do_step(step, std::integral_constant<int, 0>{});
         if (step + 1 < n_steps) do_step(step + 1, std::integral_constant<int, 1>{});
@@ -752,6 +791,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
             if (step + 9 < n_steps) do_step(step + 9, std::integral_constant<int, 9>{});
         }
     }
+    TRACE_LOOP_END();
 #ifdef DKV_STAMP
     if (lane == 0 && wave == 0) {  // DEBUG BUILD ONLY: overwrites the first floats of the workgroup's first dq row
         float* dbg = reinterpret_cast<float*>(dqkv + (row0 + kgrp * 128) * ld);
@@ -779,9 +819,17 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
             *reinterpret_cast<bf16x4*>(krow_out + db * 32 + 8 * g + 4 * h) = vk;
             *reinterpret_cast<bf16x4*>(vrow_out + db * 32 + 8 * g + 4 * h) = vv;
         }
+    TRACE_END(2, n_steps);
 }
 
 }  // namespace
+
+#ifdef ATTN_TRACE
+extern "C" int ssi_debug_attn_trace(void* dst_host, int kernel) {  // debug build only: copy one kernel's table to the host
+    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_attn_trace), sizeof(unsigned long long) * TRACE_MAX * 6,
+                                    sizeof(unsigned long long) * TRACE_MAX * 6 * (size_t)kernel, hipMemcpyDeviceToHost);
+}
+#endif
 
 bool ssi_attn_mfma_supported(int64_t ld, int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype) {
     if (dtype != SSI_BF16 || head_dim != HD) return false;

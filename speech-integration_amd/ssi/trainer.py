@@ -114,47 +114,23 @@ def resume_position(global_step: int, steps_per_epoch: int, gradient_accumulatio
 class Trainer:
     """Usage (as the reference): ``t = Trainer(cfg); t.setup(); t.train(); t.cleanup()``."""
 
+    # Attribute surface (``tests/test_trainer.py:32-74`` of the reference asserts these names): what ``setup()`` fills in starts as None,
+    # counters start at zero.  Kept as tables so that adding state means adding a row, not another assignment block.
+    _FILLED_BY_SETUP = ("model", "tokenizer", "optimizer", "lr_scheduler", "loss_fn", "checkpointer", "wandb_logger",
+                        "data_train", "sampler_train", "data_dev", "token_type_ranges", "geometry", "device", "dtype", "world_size",
+                        "grad_sync", "_grad_norm", "_loss_log", "_resume_state", "_resume_rng_state")
+    _COUNTERS = {"rank": 0, "global_step": 0, "consumed_samples": 0, "tokens_train_total": 0, "wall_clock_offset": 0.0,
+                 "loss_running": 0.0, "num_tokens_step": 0, "max_seq_len_step": 0, "t_train_start": 0.0, "t_step_start": 0.0}
+
     def __init__(self, cfg) -> None:
         self.cfg = cfg
-        # components — populated by setup()
-        self.model = None
-        self.tokenizer = None
-        self.optimizer = None
-        self.lr_scheduler = None
-        self.loss_fn = None
-        self.checkpointer = None
-        self.wandb_logger = None
-        # data
-        self.data_train = None
-        self.sampler_train = None
-        self.data_dev = None
-        self.token_type_ranges: dict[str, tuple[int, int]] | None = None
-        self.geometry: TrainingGeometry | None = None
-        # device / dtype
-        self.device: torch.device | None = None
-        self.dtype: torch.dtype | None = None
-        self.world_size: int | None = None
-        self.rank: int = 0
-        # training state
-        self.global_step: int = 0
-        self.consumed_samples: int = 0
-        self.tokens_train_total: int = 0
-        self.token_type_counts_total: defaultdict[str, int] = defaultdict(int)
-        self.wall_clock_offset: float = 0.0
-        # step-level accumulators
-        self.loss_running: float = 0.0
-        self.num_tokens_step: int = 0
-        self.max_seq_len_step: int = 0
-        self.t_train_start: float = 0.0
-        self.t_step_start: float = 0.0
-        self._grad_norm: float | None = None
-        self._loss_log: list[float] | None = None
-        self._type_counts_window: defaultdict[str, int] = defaultdict(int)  # this rank's counts since the last optimizer step
-        self._bad_inputs_window: defaultdict[str, int] = defaultdict(int)   # ids / positions the kernels had to refuse, same window
-        # data parallel
-        self.grad_sync: GradSync | None = None
-        self._resume_state: dict[str, Any] | None = None
-        self._resume_rng_state = None
+        for name in self._FILLED_BY_SETUP:
+            setattr(self, name, None)
+        for name, zero in self._COUNTERS.items():
+            setattr(self, name, zero)
+        self.token_type_counts_total: defaultdict[str, int] = defaultdict(int)   # since step 0 (restored on resume), global under DP
+        self._type_counts_window: defaultdict[str, int] = defaultdict(int)      # this rank's counts since the last optimizer step
+        self._bad_inputs_window: defaultdict[str, int] = defaultdict(int)       # ids / positions the kernels had to refuse, same window
 
     # === Setup ===========================================================================================================
     def setup(self) -> None:
@@ -397,27 +373,38 @@ class Trainer:
                 self._raise_on_bad_inputs(self._bad_inputs_window, anywhere=int(round(summed[2])))
         self._type_counts_window.clear()
         self._bad_inputs_window.clear()
-        if self.num_tokens_step == 0:
+        window_tokens = self.num_tokens_step
+        if window_tokens > 0:
+            self._apply_window(window_tokens)
+            self._close_window(epoch, iter_idx, window_tokens)
+        else:  # every label of the window ignored: nothing to learn from, nothing to count (reference: warn, drop the gradients, go on)
             LOGGER.warning("No non-ignored tokens in accumulation window; skipping optimizer step.")
             self.optimizer.zero_grad(set_to_none=True)
-            self._reset_step_accumulators()
-            return
-        scale_grads(self.model, torch.tensor(1 / self.num_tokens_step))
-        if self.cfg.clip_grad_norm is not None:
-            self._grad_norm = clip_grad_norm_(self.model, max_norm=float(self.cfg.clip_grad_norm))
+        self._reset_step_accumulators()
+        if window_tokens > 0:
+            self._maybe_save_checkpoint()
+
+    def _apply_window(self, window_tokens: int) -> None:
+        """Gradients of the window -> parameters: mean over the window's (global) unshifted token count, optional global-norm clip, AdamW,
+        schedule.  On the HIP model the scale and the clip coefficient ride into the one-kernel AdamW (``ssi.optimizer``)."""
+        scale_grads(self.model, torch.tensor(1 / window_tokens))
+        max_norm = self.cfg.clip_grad_norm
+        if max_norm is not None:
+            self._grad_norm = clip_grad_norm_(self.model, max_norm=float(max_norm))
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
+
+    def _close_window(self, epoch: int, iter_idx: int, window_tokens: int) -> None:
+        """Counters and the step's log record (``trainer.py:413-421``): one optimizer step consumed ga x batch x world samples."""
         self.global_step += 1
-        self.consumed_samples += self.cfg.gradient_accumulation_steps * self.geometry.batch_size * self.world_size
-        loss_to_log = self.loss_running / self.num_tokens_step
-        self.tokens_train_total += self.num_tokens_step
+        self.consumed_samples += self.geometry.batch_size * self.cfg.gradient_accumulation_steps * self.world_size
+        self.tokens_train_total += window_tokens
+        mean_loss = self.loss_running / window_tokens
         if self._loss_log is not None:
-            self._loss_log.append(loss_to_log)
-        self._log_metrics(epoch, iter_idx, loss_to_log)
-        self._reset_step_accumulators()
-        self._maybe_save_checkpoint()
+            self._loss_log.append(mean_loss)
+        self._log_metrics(epoch, iter_idx, mean_loss)
 
     def _evaluate(self) -> float:
         return compute_dataset_loss(self.model, self.data_dev, self.loss_fn,
