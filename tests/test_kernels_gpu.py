@@ -855,6 +855,14 @@ def test_doc_ranges_kernel_matches_the_torch_restatement(ops):
     big = torch.arange(6000).reshape(1, 6000)
     pos, _, _ = ops.doc_ranges(big.to(DEV), 4095)
     assert int(pos.max()) == 4095   # clamped to the RoPE table
+    # ... and counted (ABI v5): 6000 - 4096 positions beyond the table, plus one negative one; the counter is ADDED to
+    n_clamped = torch.full((1,), 7, dtype=torch.int32, device=DEV)
+    big[0, 3] = -2
+    pos, _, _ = ops.doc_ranges(big.to(DEV), 4095, n_clamped)
+    assert int(n_clamped) == 7 + (6000 - 4096) + 1 and int(pos.min()) == 0
+    n_clamped.zero_()
+    ops.doc_ranges(torch.arange(300).reshape(1, 300).to(DEV), 4095, n_clamped)
+    assert int(n_clamped) == 0
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -169,3 +169,29 @@ def test_cpt_trainer_with_clipping_matches_cpu_step_oracle(tmp_path, dtype, tol)
         assert b > 0.05, "the test must actually clip"
         assert abs(a - b) <= (1e-3 if dtype == "fp32" else 5e-2) * b
     t.cleanup()
+
+
+@pytest.mark.parametrize("what", ["label", "token", "position"])
+def test_ids_the_kernels_must_refuse_are_raised_by_the_trainer(tmp_path, what):
+    """torch's embedding / cross_entropy device-assert on ids outside the vocabulary; the HIP kernels write zeros, COUNT, and the trainer raises
+    from the one read-back it does per micro-batch anyway — labels and tokens outside [0, V), and packed positions beyond the RoPE table (the
+    kernel clamps them so that the table is never over-read; ADVICE r2: a clamp alone would hide the data bug)."""
+    t = _trainer(tmp_path, f"bad_{what}", overrides=["max_steps=1"])
+    V = t._llama_config.vocab_size
+    batch = {k: v.clone() for k, v in next(iter(t.data_train)).items()}
+    t._train_step({k: v.clone() for k, v in batch.items()})          # a clean micro-batch passes
+    if what == "label":
+        batch["labels"][0, 5] = V + 3
+        match = "labels outside"
+    elif what == "token":
+        batch["tokens"][1, 7] = V
+        batch["labels"][1, 7] = -100
+        match = "token ids outside"
+    else:
+        B, S = batch["tokens"].shape
+        batch["input_pos"] = torch.arange(S).expand(B, S).clone()
+        batch["input_pos"][0, S - 1] = t.model._rope.shape[0] + 10    # beyond the RoPE cache
+        match = "input_pos entries outside"
+    with pytest.raises(IndexError, match=match):
+        t._train_step(batch)
+    t.cleanup()
