@@ -84,8 +84,9 @@ class HipAdamW(torch.optim.Optimizer):
             sync.finish_deferred()
             update(lo, hi)
         m.pending_grad_scale = None
-        # the gradients are NOT zeroed (2.5 GB of writes per step for nothing): the next backward overwrites them (model protocol)
-        m._grads_dirty, m._grads_stale = False, not m.always_accumulate
+        # the gradients are NOT zeroed (2.5 GB of writes per step for nothing) and the window is NOT closed here: as with torch.optim, a
+        # backward that follows a step without a zero_grad in between accumulates; zero_grad (this optimizer's, the model's, or a foreign
+        # one that drops every p.grad) ends the window, and the first backward after it overwrites the buffer (model protocol)
         m._hip_epoch += 1  # weights changed behind torch's version counter
         if self._views_ready:
             for st in self.state.values():

@@ -165,3 +165,26 @@ def test_failed_backward_behind_the_head_does_not_leak_into_the_next_window():
     fresh = _build(params, {k: v.detach().clone() for k, v in model.state_dict().items()}, torch.float32)
     fresh.forward_hidden(tok).float().pow(2).sum().backward()
     assert torch.equal(got, fresh.tok_embeddings.weight.grad)
+
+
+def test_backward_after_a_step_without_zero_grad_accumulates_like_torch():
+    """torch.optim semantics: ``step()`` does not end the accumulation window, ``zero_grad`` does."""
+    from oracle import hf_crosscheck as hx
+    from ssi.loss import CEWithChunkedOutputLoss, compute_loss
+    from ssi.optimizer import HipAdamW
+    params = MFMA_PARAMS
+    sd = hx.seeded_state_dict(params, 9)
+    batch = {k: v.to(DEV) for k, v in hx.seeded_batch(700, 2, 128, 3).items()}
+    model = _build(params, sd, torch.float32)
+    opt = HipAdamW(model.parameters(), model=model, lr=0.0, weight_decay=0.0)   # a step that moves nothing: same weights before and after
+    compute_loss(batch, model, CEWithChunkedOutputLoss()).backward()
+    once = model._flat_grad.clone()
+    opt.step()
+    compute_loss(batch, model, CEWithChunkedOutputLoss()).backward()           # no zero_grad in between
+    fresh = _build(params, sd, torch.float32)
+    compute_loss(batch, fresh, CEWithChunkedOutputLoss()).backward()
+    compute_loss(batch, fresh, CEWithChunkedOutputLoss()).backward()
+    assert torch.equal(model._flat_grad, fresh._flat_grad) and not torch.equal(model._flat_grad, once)
+    opt.zero_grad(set_to_none=True)
+    compute_loss(batch, model, CEWithChunkedOutputLoss()).backward()           # a new window: written, not added
+    assert torch.equal(model._flat_grad, once)
