@@ -234,6 +234,61 @@ def test_bf16_gradient_error_is_the_reference_arithmetics_own_rounding():
         assert e_hip[k] <= 1.5 * e_ref[k] + 1e-3, f"{k}: HIP {e_hip[k]:.3e} vs the reference arithmetic in bf16 {e_ref[k]:.3e}"
 
 
+def test_full_width_model_on_ragged_padded_micro_batches_matches_the_cpu_oracle():
+    """The reference's batch format at the model's real widths (D = 2048, I = 8192, 32 / 8 heads, V = 133 258; 2 layers to keep the oracle at
+    seconds): right-padded rows of unequal length (``padded_collate_sft``: pad id / -100), a row whose labels are all ignored, sequence lengths
+    that are multiples of nothing (333, then 777: padded to whole MFMA tiles inside the model), two micro-batches accumulated with the trainer's
+    algebra (mean over SHIFTED labels x UNSHIFTED count) — bf16 HIP model against the fp32 oracle: per-micro-batch losses, every gradient."""
+    from oracle.llama_oracle import OracleCEWithChunkedOutputLoss, OracleLlama
+    from oracle.llama_oracle import compute_loss as oracle_loss
+    from ssi.data import synthetic_batch
+    from ssi.loss import CEWithChunkedOutputLoss, compute_loss
+    from ssi.model import HipLlamaDecoder
+    cfg = _full_config(5000)
+    cfg.num_layers = 2
+    params = cfg.parameters
+    assert params["num_layers"] == 2 and params["embed_dim"] == 2048 and params["vocab_size"] == 133_258
+    sd = _seeded_full_state_dict(params, 77)
+    pad_id = 133_006
+    batches = []
+    for (B, S), seed in (((3, 333), 1), ((2, 777), 2)):
+        b = synthetic_batch(B, S, 5000, seed=seed)
+        lens = [S, S - 100, S // 3][:B]
+        for r, n in enumerate(lens):      # right padding as the collate function does it
+            b["tokens"][r, n:] = pad_id
+            b["labels"][r, n:] = -100
+        batches.append(b)
+    batches[0]["labels"][2] = -100        # a row that contributes nothing
+    ref = OracleLlama(**params, rope_cache_len=1024)
+    ref.load_state_dict(sd)
+    ref.set_num_output_chunks(8)
+    model = HipLlamaDecoder(**params, dtype=torch.bfloat16, device=DEV, rope_cache_len=1024)
+    model.load_state_dict(sd)
+    model.set_num_output_chunks(8)
+    model.train()
+    assert model._mfma_shapes() and model.padded_seq_len(3, 333) != 333
+    n_total = 0
+    for b in batches:
+        n = int((b["labels"] != -100).sum())
+        n_total += n
+        want = oracle_loss(b, ref, OracleCEWithChunkedOutputLoss())
+        (want * n).backward()
+        got = compute_loss({k: v.to(DEV) for k, v in b.items()}, model, CEWithChunkedOutputLoss())
+        (got * n).backward()
+        rel = abs(got.item() - want.item()) / abs(want.item())
+        print(f"[ragged full-width] B x S = {tuple(b['tokens'].shape)}: loss {got.item():.6f} vs oracle {want.item():.6f} (rel {rel:.2e})")
+        assert rel <= 1e-2
+    worst, worst_key = 0.0, None
+    for (k, p), (_, p2) in zip(model.named_parameters(), ref.named_parameters()):
+        err = float((p.grad.float().cpu() - p2.grad).norm() / p2.grad.norm())
+        if err > worst:
+            worst, worst_key = err, k
+        assert err <= TOL_GRAD_BF16, f"{k}: relative gradient error {err}"
+    print(f"[ragged full-width] worst relative gradient error over two accumulated micro-batches {worst:.2e} ({worst_key}); {n_total} label tokens")
+    pad_rows = model._view("emb", None, model._flat_grad)[params["vocab_size"]:]
+    assert float(pad_rows.abs().max()) == 0.0      # the rows that pad the table to whole tiles never receive a gradient
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # 2. The step's own GEMM shapes, exact on small integers
 # ---------------------------------------------------------------------------------------------------------------------
