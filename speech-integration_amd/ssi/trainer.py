@@ -6,9 +6,9 @@ Appendix A.5): each micro-batch's mean loss over SHIFTED valid labels is multipl
 before ``backward``; at the accumulation boundary gradients are divided by the sum of unshifted counts.
 
 What differs underneath (MI355X-first):
-* one fused HIP kernel counts token types and valid labels (K14); together with the loss it is fetched with ONE
-  device->host copy per micro-batch, issued after backward has been queued (the reference blocks 7-8 times per
-  micro-batch, before and after the forward);
+* one fused HIP kernel counts token types and valid labels (K14); counts, loss and the kernels' error counts of a micro-batch stay on the
+  device, and the whole accumulation window is fetched with ONE device->host copy at its boundary (the reference blocks 7-8 times per
+  micro-batch, before and after the forward): between micro-batches the host never waits for the GPU;
 * ``scale_grads`` and the clip coefficient are folded into the single-kernel AdamW step, which also zeroes the gradients;
 * data parallelism (absent from the reference): per-layer gradient buckets all-reduced over RCCL/xGMI on a side stream
   during the last micro-batch's backward; token counts and running loss reduced with one small collective; every rank
@@ -124,13 +124,67 @@ class Trainer:
 
     def __init__(self, cfg) -> None:
         self.cfg = cfg
+        self._pending_readbacks: list[tuple[Tensor, int]] = []  # (device row of a micro-batch's counts / loss / error counts, tokens in it)
         for name in self._FILLED_BY_SETUP:
             setattr(self, name, None)
         for name, zero in self._COUNTERS.items():
             setattr(self, name, zero)
-        self.token_type_counts_total: defaultdict[str, int] = defaultdict(int)   # since step 0 (restored on resume), global under DP
+        self.token_type_counts_total = defaultdict(int)                          # since step 0 (restored on resume), global under DP
         self._type_counts_window: defaultdict[str, int] = defaultdict(int)      # this rank's counts since the last optimizer step
         self._bad_inputs_window: defaultdict[str, int] = defaultdict(int)       # ids / positions the kernels had to refuse, same window
+
+    # The window's accumulators are host numbers (the reference's attribute names), but on the GPU path a micro-batch leaves its counts and
+    # loss ON THE DEVICE: nothing in the step loop needs them before the accumulation boundary, so the host never waits for the GPU between
+    # micro-batches (the reference blocks 7-8 times per micro-batch; rounds 1-2 of this trainer once).  Reading any of the three attributes
+    # below fetches what is pending first — ONE device-to-host copy per window.
+    def _read_back_window(self) -> None:
+        if not self._pending_readbacks:
+            return
+        pending, self._pending_readbacks = self._pending_readbacks, []
+        rows = torch.stack([row for row, _ in pending]).tolist()  # the window's one host sync
+        kinds = list(self.token_type_ranges)
+        for host, (_, n_positions) in zip(rows, pending):
+            counts = {tt: int(c) for tt, c in zip(kinds + ["total"], host)}
+            for tt, c in counts.items():
+                self._token_type_counts_total[tt] += c
+                self._type_counts_window[tt] += c
+            self._num_tokens_step += int(host[len(kinds) + 1])
+            self._loss_running += float(host[-3])
+            # ids outside the vocabulary: torch's embedding / cross_entropy would device-assert (the HIP kernels write zeros and count);
+            # the token-type ranges partition [0, V), so a token outside them shows up as a short sum; positions beyond the RoPE table are
+            # clamped by the kernel and counted
+            self._bad_inputs_window["labels outside [0, vocab_size)"] += int(host[-2])
+            self._bad_inputs_window["token ids outside [0, vocab_size)"] += n_positions - sum(counts[tt] for tt in kinds)
+            self._bad_inputs_window["input_pos entries outside the RoPE table"] += int(host[-1])
+        if self.grad_sync is None:  # alone: fail here; data parallel: at the window's scalar all-reduce, on EVERY rank (a rank that raised
+            self._raise_on_bad_inputs(self._bad_inputs_window)  # alone would leave the others blocked in their collectives)
+
+    @property
+    def num_tokens_step(self) -> int:
+        self._read_back_window()
+        return self._num_tokens_step
+
+    @num_tokens_step.setter
+    def num_tokens_step(self, value: int) -> None:
+        self._num_tokens_step = value
+
+    @property
+    def loss_running(self) -> float:
+        self._read_back_window()
+        return self._loss_running
+
+    @loss_running.setter
+    def loss_running(self, value: float) -> None:
+        self._loss_running = value
+
+    @property
+    def token_type_counts_total(self):
+        self._read_back_window()
+        return self._token_type_counts_total
+
+    @token_type_counts_total.setter
+    def token_type_counts_total(self, value) -> None:
+        self._token_type_counts_total = value
 
     # === Setup ===========================================================================================================
     def setup(self) -> None:
@@ -307,7 +361,8 @@ class Trainer:
                     return
 
     def _train_step(self, batch: dict[str, Tensor], sync_gradients: bool = True) -> None:
-        """Single micro-batch forward + backward (``trainer.py:385-395``) with one host sync at the end."""
+        """Single micro-batch forward + backward (``trainer.py:385-395``).  On the GPU nothing is read back here: the counts, the loss and the
+        kernels' error counts of the micro-batch stay on the device until the window closes (``_read_back_window``)."""
         batch_to_device(batch, self.device)
         tokens, labels = batch["tokens"], batch["labels"]
         ignore = self.loss_fn.ignore_index
@@ -327,27 +382,15 @@ class Trainer:
             zero = torch.zeros(1, dtype=torch.float64, device=tokens.device)
             errs = [getattr(self.model, "label_errors", None), getattr(self.model, "position_errors", None)]
             errs = [zero if e is None else e.detach().to(torch.float64).reshape(1) for e in errs]
-            host = torch.cat((counts_dev.to(torch.float64), loss_batch.detach().to(torch.float64).reshape(1), *errs)).tolist()
-            names = list(self.token_type_ranges) + ["total"]
-            counts_host = {tt: int(c) for tt, c in zip(names, host)}
-            num_tokens_iter, loss_value = int(host[len(names)]), float(host[-3])
-            # ids outside the vocabulary: torch's embedding / cross_entropy would device-assert (the HIP kernels write zeros and count);
-            # the token-type ranges partition [0, V), so a token outside them shows up as a short sum; positions beyond the RoPE table are
-            # clamped by the kernel and counted — all read from this one copy
-            bad = {"labels outside [0, vocab_size)": int(host[-2]),
-                   "token ids outside [0, vocab_size)": tokens.numel() - sum(counts_host[tt] for tt in self.token_type_ranges),
-                   "input_pos entries outside the RoPE table": int(host[-1])}
-            for what, n_bad in bad.items():
-                self._bad_inputs_window[what] += n_bad
-            if self.grad_sync is None:  # alone: fail here; data parallel: at the window's scalar all-reduce, on EVERY rank (a rank that
-                self._raise_on_bad_inputs(self._bad_inputs_window)  # raised alone would leave the others blocked in their collectives)
-        else:
-            num_tokens_iter, loss_value = int(n_valid.item()), float(loss_batch.item())
+            # row = [count per token type ..., total (non-pad), valid labels, loss x valid labels, bad labels, bad positions]
+            row = torch.cat((counts_dev.to(torch.float64), loss_batch.detach().to(torch.float64).reshape(1), *errs))
+            self._pending_readbacks.append((row, tokens.numel()))
+            return
         for tt, c in counts_host.items():
-            self.token_type_counts_total[tt] += c
+            self._token_type_counts_total[tt] += c
             self._type_counts_window[tt] += c
-        self.num_tokens_step += num_tokens_iter
-        self.loss_running += loss_value
+        self._num_tokens_step += int(n_valid.item())
+        self._loss_running += float(loss_batch.item())
 
     @staticmethod
     def _raise_on_bad_inputs(bad: dict[str, int], anywhere: int | None = None) -> None:
@@ -358,6 +401,7 @@ class Trainer:
 
     def _optimizer_step(self, epoch: int, iter_idx: int) -> None:
         """Accumulation boundary (``trainer.py:397-424``): [all-reduce] -> scale -> clip -> AdamW -> LR -> counters."""
+        self._read_back_window()  # the window's one device-to-host copy: counts, losses and error counts of its micro-batches
         if self.grad_sync is not None:
             # one small collective: token count, running loss and the window's token-type counts (tokens_total is global, so the
             # per-type totals must be too: every rank adds what the OTHER ranks saw in this window)

@@ -174,7 +174,7 @@ def test_cpt_trainer_with_clipping_matches_cpu_step_oracle(tmp_path, dtype, tol)
 @pytest.mark.parametrize("what", ["label", "token", "position"])
 def test_ids_the_kernels_must_refuse_are_raised_by_the_trainer(tmp_path, what):
     """torch's embedding / cross_entropy device-assert on ids outside the vocabulary; the HIP kernels write zeros, COUNT, and the trainer raises
-    from the one read-back it does per micro-batch anyway — labels and tokens outside [0, V), and packed positions beyond the RoPE table (the
+    from the one read-back it does per accumulation window anyway — labels and tokens outside [0, V), and packed positions beyond the RoPE table (the
     kernel clamps them so that the table is never over-read; ADVICE r2: a clamp alone would hide the data bug)."""
     t = _trainer(tmp_path, f"bad_{what}", overrides=["max_steps=1"])
     V = t._llama_config.vocab_size
@@ -192,6 +192,7 @@ def test_ids_the_kernels_must_refuse_are_raised_by_the_trainer(tmp_path, what):
         batch["input_pos"] = torch.arange(S).expand(B, S).clone()
         batch["input_pos"][0, S - 1] = t.model._rope.shape[0] + 10    # beyond the RoPE cache
         match = "input_pos entries outside"
+    t._train_step(batch)                                              # queued: nothing is read back inside a micro-batch ...
     with pytest.raises(IndexError, match=match):
-        t._train_step(batch)
+        t.num_tokens_step                                             # ... the window's one read-back raises (here, or in _optimizer_step)
     t.cleanup()
