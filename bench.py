@@ -247,7 +247,7 @@ def self_launch(n: int) -> int:
     return proc.returncode
 
 
-def through_trainer(args) -> int:
+def through_trainer(args, result_out) -> int:
     """Secondary measurement (NOT the headline line): the same workload through the drop-in entry point — what ``scripts/train_sft.py``
     does (``/root/reference/scripts/train_sft.py:9-15``): compose ``conf/sft.yaml``, ``Trainer(cfg).setup(); .train()`` — with the device
     prefetcher, per-step logging and the reference's bookkeeping in the loop, at ``gradient_accumulation_steps`` 1 and the reference's
@@ -291,13 +291,28 @@ def through_trainer(args) -> int:
         del t
         torch.cuda.empty_cache()
         shutil.rmtree(tmp, ignore_errors=True)
-    print(json.dumps({"metric": "train_tokens_per_sec", "mode": "through_trainer", "unit": "tokens/s", "n_gpus": 1, "dtype": args.dtype,
+    result_out.emit(json.dumps({"metric": "train_tokens_per_sec", "mode": "through_trainer", "unit": "tokens/s", "n_gpus": 1, "dtype": args.dtype,
                       "data": "synthetic", "higher_is_better": True,
                       "config": {"workload": f"scripts/train_sft.py path: compose(conf/sft.yaml) -> Trainer.setup() -> Trainer.train(); Llama-3.2-1B "
                                              f"+{args.n_dsus} DSUs, seq_len={args.seq}, batch={args.batch}, prefetcher on, log_interval=1, 16 layers, "
                                              "random-init weights, MLS-shaped synthetic DSU sequences"},
-                      "value": runs["grad_accum_1"]["positions_per_second"], "runs": runs}), flush=True)
+                      "value": runs["grad_accum_1"]["positions_per_second"], "runs": runs}))
     return 0
+
+
+class _JsonOnlyStdout:
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to stdout when the first
+    communicator is created — seen on the first run that reached it, profiles/r03_s): everything this process and its libraries print goes to
+    stderr, and the result line alone is written to the original stdout."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.fd = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, line: str) -> None:
+        sys.stdout.flush()
+        os.write(self.fd, (line.rstrip("\n") + "\n").encode())
 
 
 def main() -> int:
@@ -329,8 +344,9 @@ def main() -> int:
     if world != args.gpus:
         print(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
         return 2
+    result_out = _JsonOnlyStdout()  # from here on fd 1 is stderr; only result_out.emit() reaches the real stdout
     if args.through_trainer:
-        return through_trainer(args)
+        return through_trainer(args, result_out)
     local = int(os.environ.get("SSI_LOCAL_DEVICE", local))  # rehearsal hook: several ranks on one GPU (with SSI_DIST_BACKEND=gloo)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
@@ -363,7 +379,8 @@ def main() -> int:
     model.set_num_output_chunks(loss_fn.num_output_chunks)
     opt = HipAdamW(model.parameters(), model=model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, amsgrad=False, fused=True)
     sync = None
-    if world > 1:
+    dp = world > 1 or os.environ.get("SSI_DP_SINGLE") == "1"  # SSI_DP_SINGLE=1 under torchrun --nproc-per-node 1: the RCCL calls with one rank
+    if dp:
         sync = GradSync(model._flat_grad, model.buckets)
         model.grad_sync = sync
     ranges = get_token_type_ranges(lcfg)
@@ -400,7 +417,7 @@ def main() -> int:
         return loss_run / n_tok, n_tok
 
     def barrier():
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -417,7 +434,7 @@ def main() -> int:
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
+    if dp:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -476,8 +493,8 @@ def main() -> int:
                 out["cpu_baseline"] = cpu_baseline(42_831)
             except Exception as e:  # the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": usable_cores(), "kind": "port", "sample": f"failed: {e!r}"}
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        result_out.emit(json.dumps(out))
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -27,10 +27,21 @@ def get_world_size_and_rank() -> tuple[int, int]:
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
 
 
+def _single_rank_exercise() -> bool:
+    """SSI_DP_SINGLE=1: run the data-parallel machinery (process group, communicators, bucketed all-reduces on the side stream, scalar
+    collective) with ONE rank.  A sum over one rank is the identity, so the step must equal the plain one bit for bit — the only way a one-GPU
+    box can execute the RCCL calls themselves (``tests/test_dp_nccl_gpu.py``)."""
+    return os.environ.get("SSI_DP_SINGLE", "0") == "1"
+
+
+def _exchange_active(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _single_rank_exercise())
+
+
 def init_distributed(device: torch.device, timeout_s: int = 600) -> tuple[int, int]:
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun).  No-op for single process."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not _single_rank_exercise():
         return 1, 0
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -77,7 +88,7 @@ class GradSync:
 
     @property
     def enabled(self) -> bool:
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return _exchange_active(self.group)
 
     def bucket_ready(self, name: str, lo: int, hi: int) -> None:
         if not self.enabled or name in self._done or hi <= lo:
@@ -194,7 +205,7 @@ class ModuleGradSync(GradSync):
 
 def all_reduce_scalars(values: list[float], device: torch.device, group=None) -> list[float]:
     """SUM-reduce a few host scalars across ranks (token counts, running loss) in one tiny collective."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not _exchange_active(group):
         return list(values)
     t = torch.tensor(values, dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)

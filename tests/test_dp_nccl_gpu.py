@@ -35,3 +35,29 @@ def test_rccl_step_on_every_gpu_equals_single_process_step(tmp_path):
     assert proc.returncode == 0, proc.stdout[-4000:] + proc.stderr[-4000:]
     verdict = json.loads(out.read_text())
     assert verdict["backend"] == "nccl" and verdict["world"] == n_ranks and verdict["ok_all_ranks"], verdict
+
+
+def test_single_rank_rccl_exchange_equals_the_plain_step(tmp_path):
+    """One GPU is enough to EXECUTE the RCCL calls: ``SSI_DP_SINGLE=1`` runs the whole exchange (process group with ``device_id``, second
+    communicator for the scalars, per-bucket ``all_reduce(async_op=True)`` on the side stream with its completion events, deferred embedding
+    bucket, dynamic GEMM tile order, float64 scalar collective, barrier, teardown) with world size 1, where a sum is the identity: the step must
+    equal the plain single-process step bit for bit.  Not a substitute for ranks on different GPUs — it pins the API use, the stream
+    ordering and the protocol against the real library."""
+    if torch.cuda.device_count() < 1:
+        pytest.skip("needs a GPU")
+    if torch.cuda.is_initialized():
+        pytest.skip("this process already holds the GPU: the rank must be started from a process that has not touched it")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "dp1.json"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SSI_DP_SINGLE="1")
+    env.pop("SSI_DIST_BACKEND", None)
+    env.pop("SSI_LOCAL_DEVICE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "workers", "dp_step_worker.py"), "--out", str(out)]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-4000:] + proc.stderr[-4000:]
+    verdict = json.loads(out.read_text())
+    assert verdict["backend"] == "nccl" and verdict["world"] == 1 and verdict["ok_all_ranks"], verdict
+    assert verdict["weights_max_abs_err"] == 0.0 and verdict["summed_gradient_rel_err"] == 0.0 and verdict["bytes_reduced"] > 0, verdict
