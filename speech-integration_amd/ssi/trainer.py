@@ -305,7 +305,8 @@ class Trainer:
 
     def _setup_data_parallel(self) -> None:
         """One process per GPU; gradients exchanged per bucket during backward (``ssi.distributed``)."""
-        if not self.world_size or self.world_size <= 1 or self.model is None:
+        from .distributed import _single_rank_exercise
+        if self.model is None or not self.world_size or (self.world_size <= 1 and not _single_rank_exercise()):
             return
         if hasattr(self.model, "_flat_grad"):
             self.grad_sync = GradSync(self.model._flat_grad, self.model.buckets)

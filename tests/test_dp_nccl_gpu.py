@@ -61,3 +61,35 @@ def test_single_rank_rccl_exchange_equals_the_plain_step(tmp_path):
     verdict = json.loads(out.read_text())
     assert verdict["backend"] == "nccl" and verdict["world"] == 1 and verdict["ok_all_ranks"], verdict
     assert verdict["weights_max_abs_err"] == 0.0 and verdict["summed_gradient_rel_err"] == 0.0 and verdict["bytes_reduced"] > 0, verdict
+
+
+@pytest.mark.parametrize("clip", ["null", "0.5"])
+def test_single_rank_rccl_trainer_equals_the_plain_trainer(tmp_path, clip):
+    """``Trainer.train()`` (5 optimizer steps, grad-accum 2, warm-up schedule, a dev pass; with and without global-norm clipping — the clip path
+    does not defer the embedding bucket) once plainly and once with the RCCL exchange switched on for its one rank: same losses, same dev loss,
+    same weights, bit for bit."""
+    if torch.cuda.device_count() < 1:
+        pytest.skip("needs a GPU")
+    if torch.cuda.is_initialized():
+        pytest.skip("this process already holds the GPU: the rank must be started from a process that has not touched it")
+    worker = os.path.join(ROOT, "tests", "workers", "dp_trainer_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("SSI_DIST_BACKEND", "SSI_LOCAL_DEVICE", "SSI_DP_SINGLE", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    plain_out = tmp_path / "plain.json"
+    proc = subprocess.run([sys.executable, worker, "--out", str(plain_out), "--workdir", str(tmp_path / "plain"), "--clip", clip],
+                          env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dp_out = tmp_path / "dp.json"
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), worker, "--out", str(dp_out), "--workdir", str(tmp_path / "dp"), "--clip", clip],
+                          env=dict(env, SSI_DP_SINGLE="1"), capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    plain, dp = json.loads(plain_out.read_text()), json.loads(dp_out.read_text())
+    assert not plain["exchange"] and dp["exchange"] and dp["backend"] == "nccl" and dp["bytes_reduced"] > 0
+    assert len(plain["losses"]) == 5 and dp["losses"] == plain["losses"], (plain["losses"], dp["losses"])
+    assert dp["dev_loss"] == plain["dev_loss"] and dp["tokens_total"] == plain["tokens_total"]
+    assert dp["weights_sum"] == plain["weights_sum"] and dp["weights_abs_sum"] == plain["weights_abs_sum"]
