@@ -9,7 +9,8 @@ What differs underneath (MI355X-first):
 * one fused HIP kernel counts token types and valid labels (K14); counts, loss and the kernels' error counts of a micro-batch stay on the
   device, and the whole accumulation window is fetched with ONE device->host copy at its boundary (the reference blocks 7-8 times per
   micro-batch, before and after the forward): between micro-batches the host never waits for the GPU;
-* ``scale_grads`` and the clip coefficient are folded into the single-kernel AdamW step, which also zeroes the gradients;
+* ``scale_grads`` and the clip coefficient are folded into the single-kernel AdamW step; nothing zeroes the gradient buffer (the first
+  backward of the next window overwrites it);
 * data parallelism (absent from the reference): per-layer gradient buckets all-reduced over RCCL/xGMI on a side stream
   during the last micro-batch's backward; token counts and running loss reduced with one small collective; every rank
   divides by the GLOBAL token count.
