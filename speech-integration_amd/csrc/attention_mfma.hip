@@ -14,6 +14,7 @@
 // Workgroup = 4 waves; the waves of a workgroup share one kv head (K/V tiles staged once for the 4 query heads of a GQA
 // group).  No atomics anywhere: dQ gets its own pass (recomputing S and dP) so every output has exactly one writer and
 // results are bitwise reproducible.
+#include <stdlib.h>
 #include <type_traits>
 #include "common_hip.h"
 
@@ -129,6 +130,15 @@ template <int SWZ> __device__ __forceinline__ bf16x8 frag_tr(const char* tile, i
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     s16x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, r);
+}
+
+// one half (4 of the 8 k rows: half 0 = rows kbase + 4 (l >> 5) + 0..3, half 1 = those + 8) of frag_tr: one ds_read_b64_tr_b16
+template <int SWZ> __device__ __forceinline__ s16x4 frag_tr_half(const char* tile, int kbase, int cbase, int lane, int half) {
+    const int G = lane >> 4, h = G >> 1, i = lane & 15, q = i >> 2, p = i & 3;
+    const int chunk = ((cbase + 16 * (G & 1)) >> 3) + (p >> 1);
+    const int r = kbase + 4 * h + q + 8 * half;
+    const char* a = tile + r * 128 + ((chunk ^ swz<SWZ>(r)) * 16) + 8 * (p & 1);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
 }
 
 // registers 8 s .. 8 s + 7 of a 32x32 accumulator as a bf16 operand fragment (k-step s)
@@ -822,6 +832,418 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
     TRACE_END(2, n_steps);
 }
 
+
+// =====================================================================================================================
+// backward: dK, dV — round 4: one wave per SIMD, hand-placed software pipeline
+// =====================================================================================================================
+// Same algebra, same operand images and the same summation order as attn_bwd_dkv_kernel (results are bit-identical), rebuilt around what
+// its trace said (profiles/LAB_NOTES.md, round 3): a wave was bound by its own chain  fragment reads -> S / dP -> exponentials -> dV / dK,
+// which two unsynchronised waves per SIMD overlapped only by chance (matrix pipe 41 % busy).  Here a wave has the SIMD to itself
+// (__launch_bounds__(256, 1): the whole 512-entry register file) and overlaps the chain with itself:
+//   * a wave owns 64 keys = two 32-key blocks kb; a workgroup = 256 keys of one (batch, kv head).  A UNIT = (query tile t, kb) is what a
+//     step of the old kernel was: 8 S / dP products (SP), the exponentials (SM), 8 dV / dK products (DKV).  Q / dO row and transposed
+//     fragments are read once per TILE and serve both units: half the LDS reads per product;
+//   * a PERIOD = 16 MFMAs carries three units at once: SP of unit u+1, SM of unit u spread over the 16 MFMA gaps (per gap: one scale, one
+//     exponential, one multiply, one packed conversion = 20 issue cycles beside the MFMA's 8, MI355X_MICROARCH.md "vector-instruction ISSUE cost"),
+//     DKV of unit u-1.  Units alternate kb, so S / dP need one register set per kb and no double buffer;
+//   * every MFMA is inline asm with its register class pinned (S / dP results in arch VGPRs where the vector ALU reads them, dK / dV sums and
+//     the K / V operand fragments in accumulation registers) and every gap is closed by sched_barrier(0): hipcc allocates, the order is ours;
+//   * the vector issue port is the scarce unit (8 + 20 of a gap's 32 cycles are taken), so the 32 LDS reads of a tile are SPREAD: one per gap
+//     (two in 8 of the 32 gaps), each a register's last use behind and >= 8 gaps ahead of its first use; the LDS-DMA requests (ring of 12
+//     tiles, one barrier and nine requests per wave per four tiles, counted vmcnt) go one per gap into the one half-period per tile that carries no LDS reads.  Bunched two
+//     per gap in half of the gaps (first build) the reads cost 6-11 cycles each (in-kernel stamps).
+// A wave does not skip the tiles in front of its keys (the old kernel's `return`): with one wave per SIMD nothing else could use the slot,
+// and wave 0 of the workgroup needs every tile anyway — they run masked (p = 0 adds exact zeros).
+constexpr int DKV2_RING = 12;
+constexpr int DKV2_SB = 8192 + 256;
+constexpr int DKV2_MAX_STEPS = 2048;  // tiles per workgroup = (S / 32) * rep at most: S <= 16384 at rep = 4
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    bf16x2_ v;
+    v[0] = (bf16_t)a;
+    v[1] = (bf16_t)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               bf16_t* __restrict__ dqkv, const float* __restrict__ rope,
+                                                               const int32_t* __restrict__ positions, int S, int H, int KV) {
+    constexpr int SB = DKV2_SB, RING = DKV2_RING;
+    __shared__ __attribute__((aligned(16))) char smem[RING * SB + DKV2_MAX_STEPS * 4];  // ring of [Q tile 4 KiB | dO tile 4 KiB | lse 128 B | delta 128 B], tile table
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rep = H / KV;
+    const int ngrp = S / 256;
+    int kgrp, pair_;  // low key groups (most work) are dispatched first
+    block_to_work(ngrp, (int)(gridDim.x / ngrp), kgrp, pair_);
+    const int kvh = pair_ % KV;
+    const int b = pair_ / KV;
+    const int h = lane >> 5;
+    const int64_t row0 = (int64_t)b * S;
+    const int64_t ldo = (int64_t)H * HD;
+    const int key0 = kgrp * 256 + wave * 64;
+
+    // operands and row constants exactly as in attn_bwd_dkv_kernel: -K * 2^-3 and -V as B operands, +lse / +delta as initial accumulators
+    bf16x8 kf[2][4], vf[2][4];
+    int kg[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        kg[kb] = key0 + 32 * kb + (lane & 31);
+        const bf16_t* krow = qkv + (row0 + kg[kb]) * ld + (int64_t)H * HD + (int64_t)kvh * HD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[kb][ks] = scale_frag(*reinterpret_cast<const bf16x8*>(krow + 16 * ks), -0.125f);
+            vf[kb][ks] = scale_frag(*reinterpret_cast<const bf16x8*>(krow + (int64_t)KV * HD + 16 * ks), -1.0f);
+            // from here on the fragments LIVE in accumulation registers: an "a" input alone makes hipcc keep them in arch VGPRs and copy
+            // them over (4 v_accvgpr_write) in front of every MFMA that names them
+            asm volatile("" : "=a"(kf[kb][ks]) : "0"(kf[kb][ks]));
+            asm volatile("" : "=a"(vf[kb][ks]) : "0"(vf[kb][ks]));
+        }
+    }
+    f32x16 dk[2][2], dv[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[kb][i][r] = 0.f; dv[kb][i][r] = 0.f; }
+
+    const int qb_first = kgrp * 8;                                       // first 32-query tile that sees any key of the group
+    const int per_head = S / 32 - qb_first;                              // tiles per query head (>= 8)
+    const int n_steps = per_head * rep;                                  // a multiple of 4: the host takes this kernel for rep % 4 == 0 only
+
+    // ---- LDS-DMA requests: as in attn_bwd_dkv_kernel, three per tile and wave, issued part by part ----------------------------------------
+    // Tile order: the MASKED tiles of every head first (the 8 tiles on the group's diagonal), then the rest of every head.  Two plain loops, one per form of the exponentials — not an if / else per period and not two inner loops taking turns:
+    // wherever register tuples defined in different places meet (a diamond, a loop nest), hipcc's phi elimination splits them into scalars in
+    // arch VGPRs and copies them into the accumulation registers in front of every MFMA (1 500 v_accvgpr moves and 400 scratch accesses in
+    // the loop of the first build).  The order of the sums over the tiles differs from attn_bwd_dkv_kernel's, so the two kernels agree to
+    // rounding, not bit for bit; each is reproducible run to run.
+    constexpr int n_edge = 8;                   // masked tiles per head: the group's diagonal
+    const int n_masked = n_edge * rep;          // tiles of the first loop; a multiple of 4, like n_steps
+    // tile i of the sequence -> (head << 16) | tile of the head, looked up in a table in LDS behind the ring (built once per workgroup): the
+    // requests run 6-7 tiles ahead of the products and cross heads and loops at other times, and a cursor kept in scalar registers by selects
+    // cost ~50 scalar instructions per trip, all in front of its first MFMA
+    int* seq_tab = reinterpret_cast<int*>(smem + RING * SB);
+    for (int i = tid; i < n_steps; i += 256) {
+        const int j = i < n_masked ? i : i - n_masked, len = i < n_masked ? n_edge : per_head - n_edge;
+        seq_tab[i] = ((j / len) << 16) | ((i < n_masked ? 0 : n_edge) + j % len);
+    }
+    const int irow = wave * 8 + (lane >> 3), ichunk = (lane & 7) ^ swz<SWZ_DUAL>(wave * 8 + (lane >> 3));
+    const u32x4 rs_q = buffer_rsrc(qkv + row0 * ld + (int64_t)kvh * rep * HD);
+    const u32x4 rs_do = buffer_rsrc(dout + row0 * ldo + (int64_t)kvh * rep * HD);
+    const unsigned voff_q = (unsigned)((irow * ld + ichunk * 8) * 2), voff_do = (unsigned)((irow * ldo + ichunk * 8) * 2);
+    const float* rc_base = (lane < 32 ? lse : delta) + ((int64_t)b * H + kvh * rep) * S + (lane & 31);
+    const unsigned lds_piece = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)smem + (unsigned)wave * 1024u);
+    const unsigned lds_rc = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)smem + 8192u);
+    // Requests are issued for EVERY ring position, also behind the last tile (the last tile again; the bytes go to a slot nobody reads): the
+    // counted vmcnt waits hold without a tail case, and there is no branch inside a trip — hipcc sinks the pure vector instructions of a gap
+    // across any basic-block boundary towards their users, which undoes the placement.
+    // One request = M0 (LDS destination) written one gap AHEAD of the load that uses it (issue_m0 then issue_go, as in gemm_nt4dma: written
+    // right in front of the load, every request stalls the wave's issue).
+    auto seq_at = [&](int step) __attribute__((always_inline)) { return seq_tab[step < n_steps ? step : n_steps - 1]; };  // every lane reads the same word
+    // Per trip of 4 tiles a wave issues 9 requests: the row constants of ONE of the four tiles (tile + wave: 256 B, lse | delta) FIRST, then its
+    // Q and dO pieces of the four tiles (every wave used to fetch every tile's constants: 12 requests; a request costs its wave ~40 cycles)
+    auto issue_m0 = [&](unsigned buf, int part) __attribute__((always_inline)) {  // buf = byte offset of the tile's ring slot
+        const unsigned dst = part == 0 ? lds_piece + buf : part == 1 ? lds_piece + buf + 4096 : lds_rc + buf;
+        asm volatile("s_mov_b32 m0, %0" ::"s"(dst) : "memory");
+    };
+    auto issue_go = [&](int w, int part) __attribute__((always_inline)) {  // w = table word of the tile
+        const int qrow = (qb_first + (w & 0xffff)) * 32, hoff = (w >> 16) * (HD * 2);
+        if (part == 0) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff_q), "s"(rs_q), "s"((unsigned)(qrow * (int)ld * 2 + hoff)) : "memory");
+        else if (part == 1) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff_do), "s"(rs_do), "s"((unsigned)(qrow * (int)ldo * 2 + hoff)) : "memory");
+        else {
+            const float* src = rc_base + ((w >> 16) * S + qrow);
+            asm volatile("global_load_lds_dword %0, off" ::"v"(src) : "memory");
+        }
+    };
+
+    // ---- per-tile register state ------------------------------------------------------------------------------------------------------------
+    f32x16 sacc[2], pacc[2];          // S' = lse - S and dP' = delta - dP of the unit in flight per key block
+    f32x16 rcl, rcd;                  // lse / delta of the tile whose S / dP products come next (rows = queries rowmap(r, h))
+    bf16x8 qfr[4], dfr[4];            // Q / dO row fragments of that tile
+    s16x4 dtrh[2][2][2], qtrh[2][2][2];  // [s2][db][half]: dO / Q transposed fragments of the tile whose dV / dK products come next
+    u32x4 pfu[2][2], dsu[2][2];       // [kb][s2]: P and -dS of a unit as bf16 operand fragments
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            pfu[i][j] = u32x4{0u, 0u, 0u, 0u};
+            dsu[i][j] = u32x4{0u, 0u, 0u, 0u};
+            dtrh[i][j][0] = dtrh[i][j][1] = s16x4{0, 0, 0, 0};  // the first period's dV / dK products add 0 * 0
+            qtrh[i][j][0] = qtrh[i][j][1] = s16x4{0, 0, 0, 0};
+        }
+
+    // Ring offsets of a trip as three scalars (RING = 12 is not a power of two and a trip's 4 tiles never wrap: t % 4 == 0): bytes of the slot of
+    // tile t (trip start), of tile t+4 (next trip's first) and of tile t+8 (first requested); tile t+i of the trip sits i * SB further on.
+    unsigned ring_cur = 0, ring_nxt = 4 * SB, ring_req = 8 * SB;
+    auto tile_base = [&](int i) __attribute__((always_inline)) { return smem + (i < 4 ? ring_cur + i * SB : ring_nxt); };  // i = tile - trip start, 0..4
+    // read i (0..15) of the 16 row reads of a tile: 0-3 lse (rows 4h + 8i ..+3), 4-7 delta, 8-11 Q row fragments, 12-15 dO row fragments
+    auto read_rows = [&](const char* qt, int i) __attribute__((always_inline)) {
+        const float* rcs = reinterpret_cast<const float*>(qt + 8192);
+        if (i < 4) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(rcs + 4 * h + 8 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rcl[4 * i + e] = l4[e];
+        } else if (i < 8) {
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(rcs + 32 + 4 * h + 8 * (i - 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rcd[4 * (i - 4) + e] = d4[e];
+        } else if (i < 12) qfr[i - 8] = frag_row<SWZ_DUAL>(qt, 0, i - 8, lane);
+        else dfr[i - 12] = frag_row<SWZ_DUAL>(qt + 4096, 0, i - 12, lane);
+    };
+    // read i (0..15) of the 16 transposed reads of a tile, in the order the dV / dK products use them: fragment i >> 1, half i & 1
+    auto read_tr = [&](const char* qt, int i) __attribute__((always_inline)) {
+        const int j = i >> 1, s2 = j >> 2, db = (j >> 1) & 1;
+        if (j & 1) qtrh[s2][db][i & 1] = frag_tr_half<SWZ_DUAL>(qt, s2 * 16, db * 32, lane, i & 1);
+        else dtrh[s2][db][i & 1] = frag_tr_half<SWZ_DUAL>(qt + 4096, s2 * 16, db * 32, lane, i & 1);
+    };
+    auto tr_frag = [&](const s16x4 (&hv)[2]) {
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(hv[0], hv[1], 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // S / dP product m (0..7) of key block kb: the S chain first (m = 0..3 = k-slices), then the dP chain; the first of a chain takes the row
+    // constants as C.  S first because the exponentials of the next period start with S: its last product is 4 MFMAs (128 cycles) old when the
+    // first scale reads it, dP's last product >= 52 cycles when the first multiply does (asm MFMAs are invisible to hipcc's hazard
+    // recogniser; an MFMA result needs 44).
+    auto sp_mfma = [&](int kb, int m) __attribute__((always_inline)) {
+        const int ks = m & 3;
+        if (m == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sacc[kb]) : "v"(qfr[0]), "a"(kf[kb][0]), "v"(rcl));
+        else if (m == 4) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(pacc[kb]) : "v"(dfr[0]), "a"(vf[kb][0]), "v"(rcd));
+        else if (m > 4) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(pacc[kb]) : "v"(dfr[ks]), "a"(vf[kb][ks]));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[kb]) : "v"(qfr[ks]), "a"(kf[kb][ks]));
+    };
+    // dV / dK product j (0..7) of key block kb, in attn_bwd_dkv_kernel's order: for s2: for db: dV, dK
+    auto dkv_mfma = [&](int kb, int j) __attribute__((always_inline)) {
+        const int s2 = j >> 2, db = (j >> 1) & 1;
+        if (j & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dk[kb][db]) : "v"(tr_frag(qtrh[s2][db])), "v"(dsu[kb][s2]));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dv[kb][db]) : "v"(tr_frag(dtrh[s2][db])), "v"(pfu[kb][s2]));
+    };
+    // exponentials of unit (tile at q0, kb), gap g of 16: scale + exponential of element g, -dS of element g - 1, one packed conversion
+    float pv[16], dsv[16];
+    auto sm_gap = [&](auto edge_c, int kb, int q0, int g) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_c)::value;
+        {
+            float p = __builtin_amdgcn_exp2f(sacc[kb][g] * -LOG2E);
+            if (EDGE) {
+                const int q = q0 + rowmap(g, h);
+                if (kg[kb] > q) p = 0.f;  // keys beyond the query contribute nothing
+            }
+            pv[g] = p;
+        }
+        if (g >= 1) dsv[g - 1] = pacc[kb][g - 1] * pv[g - 1];
+        if (g >= 2 && !(g & 1)) { const int j = (g - 2) >> 1; pfu[kb][j >> 2][j & 3] = pack_bf16(pv[g - 2], pv[g - 1]); }
+        if (g >= 3 && (g & 1)) { const int j = (g - 3) >> 1; dsu[kb][j >> 2][j & 3] = pack_bf16(dsv[g - 3], dsv[g - 2]); }
+        if (g == 15) {
+            dsv[15] = pacc[kb][15] * pv[15];
+            pfu[kb][1][3] = pack_bf16(pv[14], pv[15]);
+            dsu[kb][1][3] = pack_bf16(dsv[14], dsv[15]);
+        }
+    };
+
+    // -DDKV2_STAMP (debug build, tools/attn_dkv_check.py stamps): cycle totals of wave 0 per half-period, by kind of tile (with / without the
+    // barrier), left in the first floats of the workgroup's first dq row.  The stamp waits for the LDS reads in flight: read shares, not lengths.
+#ifdef DKV2_STAMP
+    unsigned long long st2_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st2_last = __builtin_readcyclecounter();
+    const unsigned long long st2_begin = st2_last;
+#define STAMP2(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); st2_acc[i] += now_ - st2_last; st2_last = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP2(i) {}
+#endif
+#ifdef DKV2_STAMP_GAPS  // debug build: cycles per GAP of the periods of a tile without barrier / requests (wave 0), 32 totals
+    unsigned long long sg_acc[32];
+    for (int i = 0; i < 32; ++i) sg_acc[i] = 0;
+    unsigned long long sg_last = __builtin_readcyclecounter();
+#define STAMPG(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); sg_acc[i] += now_ - sg_last; sg_last = now_; __builtin_amdgcn_sched_barrier(0); }
+#define STAMPG_RESET() { __builtin_amdgcn_sched_barrier(0); sg_last = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#define STAMPG_ON 1
+#else
+#define STAMPG_ON 0
+#define STAMPG(i) {}
+#define STAMPG_RESET() {}
+#endif
+    // period A of tile t: SM of unit (t, 0);  MFMAs 0-7 = dV / dK of (t-1, 1), 8-15 = S / dP of (t, 1) — the products whose results the vector
+    // ALU needs come LAST, so that at most ~1.4 S / dP register sets are live at any time (first-half S / dP put 296 registers in flight and the
+    // fragments into scratch).  Behind MFMA 7: the ring barrier (every second tile).  LDS reads: one transposed read of tile t per gap (fragment
+    // j right behind the last use of tile t-1's fragment j), and from gap 10 on also the row constants of tile t+1
+    auto period_a = [&](auto edge_c, auto sync_c, auto pos_c, int t, int q0) __attribute__((always_inline)) {
+        constexpr int POS = decltype(pos_c)::value;  // position of tile t in its trip
+        const char* ct_ = tile_base(POS);
+        const char* nt_ = tile_base(POS + 1);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (m < 8) dkv_mfma(1, m);
+            else sp_mfma(1, m - 8);
+            sm_gap(edge_c, 0, q0, m);
+            if (m == 7 && decltype(sync_c)::value) {
+                __builtin_amdgcn_sched_barrier(0);
+                // own requests of tiles t+1 .. t+4 have landed — the Q / dO pieces of t+5, t+6, t+7 stay in flight; the row constants of
+                // t+4 .. t+7 were this wave's FIRST request of the last trip ...
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                ring_barrier();  // ... and everybody's; every wave is done with tiles t-4 .. t-1: their slots are free
+            }
+            read_tr(ct_, m);                      // fragment m >> 1 of tile t-1 had its last use in MFMA m >> 1
+            if (m >= 10) read_rows(nt_, m - 10);  // lse 0-3, delta 0-1 of tile t+1
+            // An MFMA reads its C operand over its whole run and hipcc does not know the asm is one: left to itself it handed the registers of
+            // lse / delta (dead to it behind MFMA 8 / 12) to the very next vector instruction, and the products ran on a half-overwritten C.
+            // Keep them alive for two more gaps (64 cycles).
+            if (m == 9) asm volatile("" ::"v"(rcl));
+            if (m == 13) asm volatile("" ::"v"(rcd));
+            __builtin_amdgcn_sched_barrier(0);
+            if (m == 7) STAMP2(decltype(sync_c)::value ? 0 : 4)
+            if (STAMPG_ON && !decltype(sync_c)::value && t % 4 == 3) STAMPG(m)
+        }
+        STAMP2(decltype(sync_c)::value ? 1 : 5)
+    };
+    // period B of tile t: SM of unit (t, 1);  MFMAs 0-7 = dV / dK of (t, 0), 8-15 = S / dP of (t+1, 0);  row constants and row fragments of tile
+    // t+1 under the first half (constants first: they are the C operands of MFMAs 8 and 9), the LDS-DMA requests of tiles t+RING-2, t+RING-1
+    // (every second tile) under the second, which carries no LDS reads
+    auto period_b = [&](auto edge_c, auto issue_c, int t, int q0) __attribute__((always_inline)) {
+        const char* nt_ = tile_base(decltype(issue_c)::value + 1);
+        int wv0 = 0, wv1 = 0, w0 = 0, w1 = 0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (m < 8) dkv_mfma(0, m);
+            else sp_mfma(0, m - 8);
+            sm_gap(edge_c, 1, q0, m);
+            if (m < 2) read_rows(nt_, 6 + m);  // delta 2-3
+            if (m < 8) read_rows(nt_, 8 + m);  // Q / dO row fragments, each 8 gaps ahead of its product
+            {   // requests for tile t + RING - 4 (its slot was freed by this trip's barrier); in the trip's first tile also the row constants
+                constexpr int KIND = decltype(issue_c)::value;  // position of tile t in its trip
+                const int rt = t + RING - 4;
+                if (m == 0) { wv0 = seq_at(rt); if (KIND == 0) wv1 = seq_at(rt + wave); }
+                if (m == 6) { w0 = __builtin_amdgcn_readfirstlane(wv0); if (KIND == 0) w1 = __builtin_amdgcn_readfirstlane(wv1); }
+                if (KIND == 0) {
+                    if (m == 8) issue_go(w1, 2);
+                    if (m == 9 || m == 10) issue_go(w0, m - 9);
+                    if (m == 7) issue_m0(ring_req + (unsigned)wave * SB, 2);
+                    if (m == 8 || m == 9) issue_m0(ring_req, m - 8);
+                } else {
+                    if (m == 9 || m == 10) issue_go(w0, m - 9);
+                    if (m == 8 || m == 9) issue_m0(ring_req + KIND * SB, m - 8);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (m == 7) STAMP2(decltype(issue_c)::value == 0 ? 2 : 6)
+            if (decltype(issue_c)::value == 3) STAMPG(16 + m)
+        }
+        STAMP2(decltype(issue_c)::value == 0 ? 3 : 7)
+        if (decltype(issue_c)::value == 2) STAMPG_RESET()
+    };
+
+    // ---- prologue ---------------------------------------------------------------------------------------------------------------------------
+    // Everything this wave has loaded from global memory is consumed HERE: hipcc does not see the LDS-DMA requests below, and its wait for a
+    // value first used inside the loops (packed rows' document ends, when this kernel still took them) was `s_waitcnt vmcnt(0)` in every trip.
+    asm volatile("" ::"v"(kg[0]), "v"(kg[1]) : "memory");
+    __syncthreads();  // the table is complete (nothing is in flight yet that a vmcnt(0) could drain)
+    // tiles 0 .. RING-5: this wave's two row-constant requests first (tiles wave and wave + 4), then its Q / dO pieces
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int w = __builtin_amdgcn_readfirstlane(seq_at(wave + 4 * i));
+        issue_m0((unsigned)(wave + 4 * i) * SB, 2);
+        asm volatile("s_nop 0" ::: "memory");
+        issue_go(w, 2);
+    }
+#pragma unroll
+    for (int i = 0; i < RING - 4; ++i) {
+        const int w = __builtin_amdgcn_readfirstlane(seq_at(i));
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            issue_m0((unsigned)i * SB, part);
+            asm volatile("s_nop 0" ::: "memory");
+            issue_go(w, part);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING - 4) - 2) : "memory");  // this wave's constants and its pieces of tile 0 have landed
+    ring_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) read_rows(smem, i);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7" ::: "memory");  // the K / V fragments reach the asm MFMAs through v_accvgpr_write: let the last one land
+#pragma unroll
+    for (int m = 0; m < 8; ++m) sp_mfma(0, m);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // asm MFMAs are opaque to the hazard recogniser: S / dP of unit (0, 0) must have landed
+
+    // ---- main loops: four tiles per trip (one barrier, nine requests per wave); a trip is ONE basic block ------------------------------------
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    int cur_qt = 0;  // tile of the head in the masked loop (the other loop needs no query positions)
+    auto trip = [&](auto edge_c, int t) __attribute__((always_inline)) {
+        int q0[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            q0[i] = (qb_first + cur_qt) * 32;
+            cur_qt = cur_qt + 1 == n_edge ? 0 : cur_qt + 1;
+        }
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        using P2 = std::integral_constant<int, 2>;
+        using P3 = std::integral_constant<int, 3>;
+        period_a(edge_c, T_{}, P0{}, t, q0[0]);
+        period_b(edge_c, P0{}, t, q0[0]);
+        period_a(edge_c, F_{}, P1{}, t + 1, q0[1]);
+        period_b(edge_c, P1{}, t + 1, q0[1]);
+        period_a(edge_c, F_{}, P2{}, t + 2, q0[2]);
+        period_b(edge_c, P2{}, t + 2, q0[2]);
+        period_a(edge_c, F_{}, P3{}, t + 3, q0[3]);
+        period_b(edge_c, P3{}, t + 3, q0[3]);
+        ring_cur = ring_nxt;
+        ring_nxt = ring_req;
+        ring_req = ring_req == 8 * SB ? 0u : ring_req + 4 * SB;
+    };
+    int t = 0;
+    for (; t < n_masked; t += 4) trip(T_{}, t);
+    for (; t < n_steps; t += 4) trip(F_{}, t);
+    // ---- drain: dV / dK of the last unit ----------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dkv_mfma(1, j);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");  // results landed; no request of this wave is left in flight towards LDS
+#ifdef DKV2_STAMP
+    const unsigned long long st2_total = __builtin_readcyclecounter() - st2_begin;
+#endif
+
+    const float* tb0 = rope ? rope : nullptr;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        bf16_t* krow_out = dqkv + (row0 + kg[kb]) * ld + (int64_t)H * HD + (int64_t)kvh * HD;
+        bf16_t* vrow_out = krow_out + (int64_t)KV * HD;
+        const float* tb = tb0 ? tb0 + (int64_t)(positions ? positions[row0 + kg[kb]] : kg[kb]) * HD : nullptr;  // dK leaves in pre-RoPE space
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 vk, vv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vk[e] = (bf16_t)(dk[kb][db][4 * g + e] * -0.125f);  // dk holds -sum dS Q
+                    vv[e] = (bf16_t)dv[kb][db][4 * g + e];
+                }
+                if (tb) vk = unrope4(vk, tb, db * 32 + 8 * g + 4 * h);
+                *reinterpret_cast<bf16x4*>(krow_out + db * 32 + 8 * g + 4 * h) = vk;
+                *reinterpret_cast<bf16x4*>(vrow_out + db * 32 + 8 * g + 4 * h) = vv;
+            }
+    }
+#ifdef DKV2_STAMP
+    if (wave == 0 && lane == 0) {  // DEBUG BUILD ONLY: overwrites the first floats of the workgroup's first dq row
+        float* dbg = reinterpret_cast<float*>(dqkv + (row0 + kgrp * 256) * ld);
+        for (int i = 0; i < 8; ++i) dbg[i] = (float)st2_acc[i];
+        dbg[8] = (float)st2_total;
+        dbg[9] = (float)n_steps;
+        dbg[10] = (float)kgrp;
+    }
+#endif
+#ifdef DKV2_STAMP_GAPS
+    if (wave == 0 && lane == 0) {  // DEBUG BUILD ONLY
+        float* dbg = reinterpret_cast<float*>(dqkv + (row0 + kgrp * 256) * ld);
+        for (int i = 0; i < 32; ++i) dbg[i] = (float)sg_acc[i];
+        dbg[32] = (float)n_steps;
+    }
+#endif
+}
+
 }  // namespace
 
 #ifdef ATTN_TRACE
@@ -860,8 +1282,18 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * n_kv * (seq / (32 * qpw)))), dim3(64 * ANW), 0, st, (const bf16_t*)qkv,
                        ld, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_start, rope, positions, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(batch * n_kv * (seq / 128))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
-                       (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, rope, positions, (int)seq, n_heads, n_kv);
+    // dK / dV: the pipelined one-wave-per-SIMD kernel where its shape assumptions hold (256-key groups, an even number of tiles per group);
+    // SSI_ATTN_DKV=1 (read per call: in-run A/B) keeps the round-1..3 kernel
+    const char* sel = getenv("SSI_ATTN_DKV");
+    // (plain causal rows only: packed rows keep the 128-key kernel, whose waves skip the tiles outside their keys' documents — at B = 2,
+    //  S = 8192 with documents of 440-1100 tokens the 256-key groups of this one, masking instead of skipping, took 409 us against 329)
+    const bool v2 = !doc_end && seq % 256 == 0 && rep % 4 == 0 && (seq / 32) * rep <= DKV2_MAX_STEPS && !(sel && sel[0] == '1');
+    if (v2)
+        hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3((unsigned)(batch * n_kv * (seq / 256))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
+                           (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, rope, positions, (int)seq, n_heads, n_kv);
+    else
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(batch * n_kv * (seq / 128))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
+                           (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, rope, positions, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
     return SSI_OK;
 }

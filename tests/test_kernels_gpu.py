@@ -527,6 +527,48 @@ def test_attention_mfma_fwd_bwd(ops, B, S, H, KV):
         ops.set_impl(prev)
 
 
+@pytest.mark.parametrize("B,S,H,KV", [(3, 256, 4, 1), (2, 512, 8, 2), (1, 1024, 32, 8), (2, 2048, 8, 2)])
+@pytest.mark.parametrize("fused_rope", [False, True])
+def test_attention_dkv_pipelined_kernel_matches_the_128_key_kernel(ops, B, S, H, KV, fused_rope, monkeypatch):
+    """Round 4: dK / dV on the one-wave-per-SIMD pipelined kernel (256-key groups, masked diagonal tiles first) against the round-1..3
+    kernel on the same inputs.  Same products and operands, another order of the sums over the query tiles: equal to fp32 rounding of
+    the sums (the bf16 results differ by at most one bf16 step), the dQ block untouched, and reproducible run to run.  S = 256 has no
+    unmasked tile at all, 4 query heads per kv head as the kernel requires (other ratios fall back to the old kernel: covered by
+    test_attention_mfma_fwd_bwd)."""
+    from ssi import _lib
+    hd = 64
+    qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=61)
+    qkv[S // 2 + 3, H * hd: H * hd + hd] *= 6.0
+    do = rnd(B * S, H * hd, dtype=torch.bfloat16, seed=62)
+    table = pos = None
+    if fused_rope:
+        table = rnd(S + 8, hd // 2, 2, dtype=torch.float32, seed=63).to(DEV)  # [position][pair][cos, sin]; any values do: the map is linear
+    prev = ops.set_impl(_lib.IMPL_MFMA)
+    try:
+        x, dout = qkv.to(DEV), do.to(DEV)
+        out = torch.empty(B * S, H * hd, dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+        delta = torch.empty_like(lse)
+        ops.attn_fwd(x, out, lse, B, S, H, KV, hd)
+        res = {}
+        for sel in ("1", "0", "0"):
+            monkeypatch.setenv("SSI_ATTN_DKV", sel)
+            d = torch.full_like(x, float("nan"))
+            ops.attn_bwd(x, out, dout, lse, d, delta, B, S, H, KV, hd, rope_table=table, positions=pos)
+            res.setdefault(sel, []).append(d.cpu().float())
+    finally:
+        ops.set_impl(prev)
+    old, (new, new2) = res["1"][0], res["0"]
+    assert torch.isfinite(new).all()
+    assert torch.equal(new, new2), "not reproducible"
+    assert torch.equal(old[:, : H * hd], new[:, : H * hd]), "the dQ block belongs to the other kernel"
+    a, b = old[:, H * hd:], new[:, H * hd:]
+    assert not torch.equal(a, b) or S == 256, "the pipelined kernel did not run"
+    rel = float((a - b).norm() / a.norm())
+    assert rel <= 3e-4, rel
+    assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max()), "more than a bf16 step apart"
+
+
 def _doc_arrays(seq_lens_rows, S):
     """doc_start / doc_end (int32 [B*S]) from per-row lists of document lengths (each row sums to S)."""
     ds, de = [], []

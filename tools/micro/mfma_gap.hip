@@ -1,0 +1,69 @@
+// What does one MFMA "gap" cost on gfx950 when the vector ALU works beside the matrix pipe?  One wave per SIMD (256-thread workgroup per CU,
+// __launch_bounds__(256, 1)), a loop of gaps { v_mfma_f32_32x32x16_bf16 ; v_mul ; v_exp ; v_mul ; v_cvt_pk } as in the pipelined attention
+// backward, by the register class of the MFMA's operands.  Cycles per gap from s_memtime (wave 0 of workgroup 0), every CU busy.
+// build: hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_gap.hip -o tools/micro/mfma_gap ; run on an MI355X
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+#define VALU4 "v_mul_f32 %[x0], %[c], %[x0]\n v_exp_f32 %[x1], %[x1]\n v_mul_f32 %[x2], %[x2], %[x3]\n v_cvt_pk_bf16_f32 %[x4], %[x5], %[x6]\n"
+#define VOPS [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [x3] "+v"(x3), [x4] "+v"(x4), [x5] "+v"(x5), [x6] "+v"(x6)
+
+// MODE 0: A = v, B = a, C/D = v (S / dP products)   1: A = v, B = v, C/D = a (dV / dK products)   2: A = a, B = v, C/D = a
+// MODE 3: A = v, B = v, C/D = v                      VALU: vector instructions beside the MFMA or not
+template <int MODE, bool VALU> __global__ __launch_bounds__(256, 1) void k(const float* in, float* out, uint64_t* cyc, int iters) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = in[threadIdx.x] + r + i;
+    u32x4 av = {threadIdx.x, 1u, 2u, 3u}, bv = {5u, threadIdx.x, 7u, 9u};
+    u32x4 aa = av, ba = bv;
+    asm volatile("" : "=a"(aa) : "0"(aa));
+    asm volatile("" : "=a"(ba) : "0"(ba));
+    if (MODE == 1 || MODE == 2)
+        for (int i = 0; i < 4; ++i) asm volatile("" : "=a"(acc[i]) : "0"(acc[i]));
+    float x0 = in[threadIdx.x], x1 = x0 * 0.5f, x2 = x0 + 2, x3 = x0 + 3, x4 = 0, x5 = x0 + 5, x6 = x0 + 6;
+    const float c = -1.44269504f;
+    const uint64_t t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (MODE == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(av), "a"(ba));
+            if (MODE == 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[g & 3]) : "v"(av), "v"(bv));
+            if (MODE == 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[g & 3]) : "a"(aa), "v"(bv));
+            if (MODE == 3) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(av), "v"(bv));
+            if (VALU) asm volatile(VALU4 : VOPS : [c] "v"(c));
+        }
+    }
+    const uint64_t t1 = __builtin_readcyclecounter();
+    asm volatile("s_nop 15\n s_nop 15");
+    float s = x0 + x1 + x2 + x3 + x4 + x5 + x6;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <typename K> double run(K kern, const char* name) {
+    float *in, *out; uint64_t* cyc;
+    const int iters = 2000;
+    hipMalloc(&in, 4096); hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 8);
+    hipMemset(in, 0, 4096);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, in, out, cyc, iters);
+    hipDeviceSynchronize();
+    uint64_t h; hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+    hipFree(in); hipFree(out); hipFree(cyc);
+    const double per = (double)h / (iters * 8.0);
+    printf("%-46s %.1f cycles per gap\n", name, per);
+    return per;
+}
+int main() {
+    run(k<0, false>, "A=v B=a C/D=v, MFMA alone");
+    run(k<1, false>, "A=v B=v C/D=a, MFMA alone");
+    run(k<0, true>, "A=v B=a C/D=v, + mul exp mul cvt_pk");
+    run(k<1, true>, "A=v B=v C/D=a, + mul exp mul cvt_pk");
+    run(k<2, true>, "A=a B=v C/D=a, + mul exp mul cvt_pk");
+    run(k<3, true>, "A=v B=v C/D=v, + mul exp mul cvt_pk");
+    return 0;
+}
