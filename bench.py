@@ -331,6 +331,9 @@ def main() -> int:
     ap.add_argument("--padded", action="store_true",
                     help="secondary workload (SURVEY.md §8d): sequence lengths ~U(0.4 S, S), right-padded to the batch maximum; "
                          "tokens/s then counts NON-PAD tokens.  Not the headline line.")
+    ap.add_argument("--no-unpad", action="store_true",
+                    help="with --padded: run the right-padded rows as they are (the round-1..3 behaviour) instead of dropping the padding on the "
+                         "host as the trainer's prefetch thread does (ssi/data/unpad.py)")
     ap.add_argument("--through-trainer", action="store_true",
                     help="secondary line: the workload through Trainer.setup()/train() (the scripts/train_sft.py path) at grad-accum 1 and 4; "
                          "one GPU.  Not the headline line.")
@@ -391,8 +394,11 @@ def main() -> int:
         batches = [{k: (v.to(device) if torch.is_tensor(v) else v)
                     for k, v in synthetic_packed_batch(args.batch, args.seq, args.n_dsus, seed=42_831 + i, rank=rank).items()} for i in range(min(n_total, 4))]
     else:
-        batches = [{k: v.to(device) for k, v in synthetic_batch(args.batch, args.seq, args.n_dsus, rank=rank, index=i % 4,
-                                                                fixed_len=not args.padded).items()} for i in range(min(n_total, 4))]
+        from ssi.data import loss_inputs, unpad_batch
+        host = [synthetic_batch(args.batch, args.seq, args.n_dsus, rank=rank, index=i % 4, fixed_len=not args.padded) for i in range(min(n_total, 4))]
+        if args.padded and not args.no_unpad:  # what the trainer's prefetch thread does to a right-padded batch before it is copied over
+            host = [unpad_batch(b, pad_id=pad_id, padded_len=model.padded_seq_len) for b in host]
+        batches = [{k: v.to(device) for k, v in b.items()} for b in host]
     if os.environ.get("SSI_BENCH_TILE_ORDER"):  # diagnostic: price of the data-parallel tile order on one GPU ("dynamic" | "static")
         from ssi import ops as _ops
         _ops.set_gemm_tile_order(dynamic=os.environ["SSI_BENCH_TILE_ORDER"] == "dynamic")
@@ -404,7 +410,7 @@ def main() -> int:
         b = batches[i % len(batches)]
         counts = count_token_types_async(b["tokens"], ranges, pad_id, b["labels"], -100)
         model.sync_this_backward = True
-        loss_batch = compute_loss(b, model, loss_fn) * counts[-1]
+        loss_batch = compute_loss(loss_inputs(b) if not args.packed else b, model, loss_fn) * counts[-1]
         loss_batch.backward()
         host = torch.cat((counts.double(), loss_batch.detach().double().reshape(1))).tolist()  # the step's one D2H sync
         n_tok, loss_run = int(host[-2]), host[-1]
@@ -459,7 +465,8 @@ def main() -> int:
             "config": {"workload": f"Llama-3.2-1B +{args.n_dsus} DSUs (V={lcfg.vocab_size}), SFT step fwd+bwd+AdamW, seq_len={args.seq}, "
                                    f"batch={args.batch}/GPU, grad_accum=1, {args.layers} layers, random-init weights, MLS-shaped synthetic DSU sequences"
                                    + (", rows packed with 440-1100-token documents (block-causal attention)" if args.packed else "")
-                                   + (", lengths ~U(0.4 S, S) right-padded, non-pad tokens counted" if args.padded else ""),
+                                   + (", lengths ~U(0.4 S, S) right-padded, non-pad tokens counted" if args.padded else "")
+                                   + (", padding dropped on the host (ssi/data/unpad.py)" if args.padded and not args.no_unpad else ""),
                        "global_batch": args.batch * world, "seq_len": args.seq, "parallelism": f"dp{world}", "last_loss": loss},
         }
         if f_tok:

@@ -23,11 +23,12 @@ from .packed import PackedDataset, pack_dataset, packed_block_causal_mask, padde
 from .prefetch import DevicePrefetcher
 from .sft import InputOutputToMessages, SFTDataset
 from .sources import load_dataset_subset
+from .unpad import loss_inputs, unpad_batch
 from .synthetic import SyntheticDSUDataset, padded_collate_sft, setup_synthetic_data, synthetic_batch, synthetic_packed_batch
 
 LOGGER = logging.getLogger(__name__)
 
-__all__ = ["SyntheticDSUDataset", "padded_collate_sft", "setup_synthetic_data", "synthetic_batch", "synthetic_packed_batch", "DevicePrefetcher",
+__all__ = ["unpad_batch", "loss_inputs", "SyntheticDSUDataset", "padded_collate_sft", "setup_synthetic_data", "synthetic_batch", "synthetic_packed_batch", "DevicePrefetcher",
            "PackedDataset", "pack_dataset", "packed_block_causal_mask", "padded_collate_packed", "SFTDataset", "InputOutputToMessages",
            "TextCompletionDataset", "CompletionSequenceType", "interleave", "concatenate_speech_text", "get_span_idxs_binomial",
            "load_dataset_subset", "setup_sft_data", "setup_text_completion_data"]

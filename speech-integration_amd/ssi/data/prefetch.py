@@ -6,13 +6,15 @@ with a blocking ``.to(device)`` inside the step, ``ssi/trainer.py:386``).
 to ``device`` with ``non_blocking=True`` on a side stream; the consumer receives device-resident batches in the loader's order
 and its compute stream is made to wait on the copy's event only (no host synchronisation).  Non-tensor values (lists of ids,
 ``seq_lens``) pass through.  Exceptions of the loader re-raise in the consumer.  On a CPU device it degrades to a plain
-background-thread prefetch (used by the CPU tests)."""
+background-thread prefetch (used by the CPU tests).  ``transform`` (optional) is applied to every HOST batch in the background
+thread before it is pinned and copied — the trainer passes ``ssi.data.unpad.unpad_batch`` there, which needs the rows' lengths and
+gets them without a device sync."""
 
 from __future__ import annotations
 
 import queue
 import threading
-from typing import Any, Iterable, Iterator
+from typing import Any, Callable, Iterable, Iterator, Optional
 
 import torch
 
@@ -20,10 +22,11 @@ _END = object()
 
 
 class DevicePrefetcher:
-    def __init__(self, loader: Iterable[dict[str, Any]], device: torch.device | str, depth: int = 2) -> None:
+    def __init__(self, loader: Iterable[dict[str, Any]], device: torch.device | str, depth: int = 2,
+                 transform: Optional[Callable[[dict[str, Any]], dict[str, Any]]] = None) -> None:
         if depth < 1:
             raise ValueError("depth must be >= 1")
-        self.loader, self.device, self.depth = loader, torch.device(device), int(depth)
+        self.loader, self.device, self.depth, self.transform = loader, torch.device(device), int(depth), transform
         if self.device.type == "cuda" and self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
 
@@ -68,6 +71,8 @@ class DevicePrefetcher:
                 if self.device.type == "cuda":
                     torch.cuda.set_device(self.device)
                 for batch in self.loader:
+                    if self.transform is not None:
+                        batch = self.transform(batch)
                     if not put(self._move(batch, stream)):
                         return
                 put(_END)

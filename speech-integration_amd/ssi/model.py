@@ -416,7 +416,7 @@ class HipLlamaDecoder(nn.Module):
             pos, ds, de = ops.doc_ranges(input_pos.to(tokens.device), self._rope.shape[0] - 1, self.position_errors)  # one launch
         T, D, I = B * S, self.embed_dim, self.intermediate_dim
         H, KV, hd, dt, A = self.num_heads, self.num_kv_heads, self.head_dim, self.dtype, self._arena
-        if S > self._rope.shape[0]:
+        if pos is None and S > self._rope.shape[0]:  # implicit positions 0 .. S-1; with input_pos the table is indexed by (clamped) positions
             raise ValueError(f"sequence length {S} exceeds the RoPE cache ({self._rope.shape[0]})")
         tok = tokens.reshape(-1).contiguous()
         L = self.num_layers

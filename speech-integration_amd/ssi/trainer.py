@@ -36,6 +36,7 @@ from torch import Tensor
 from . import __version__
 from .constants import DEBUGGING_TAG, MODEL_KEY, SEED
 from .distributed import GradSync, all_reduce_scalars, get_world_size_and_rank, init_distributed
+from .data.unpad import loss_inputs
 from .eval import batch_to_device, compute_dataset_loss
 from .llama_configs import configllama3_2_1b
 from .loss import CEWithChunkedOutputLoss, compute_loss
@@ -121,7 +122,8 @@ class Trainer:
                         "data_train", "sampler_train", "data_dev", "token_type_ranges", "geometry", "device", "dtype", "world_size",
                         "grad_sync", "_grad_norm", "_loss_log", "_resume_state", "_resume_rng_state")
     _COUNTERS = {"rank": 0, "global_step": 0, "consumed_samples": 0, "tokens_train_total": 0, "wall_clock_offset": 0.0,
-                 "loss_running": 0.0, "num_tokens_step": 0, "max_seq_len_step": 0, "t_train_start": 0.0, "t_step_start": 0.0}
+                 "loss_running": 0.0, "num_tokens_step": 0, "max_seq_len_step": 0, "t_train_start": 0.0, "t_step_start": 0.0,
+                 "unpadded_micro_batches": 0}
 
     def __init__(self, cfg) -> None:
         self.cfg = cfg
@@ -346,10 +348,23 @@ class Trainer:
         depth = int(self.cfg.get("prefetch_batches", 2) or 0)
         if self.device.type == "cuda" and depth > 0:
             from .data.prefetch import DevicePrefetcher
-            source = DevicePrefetcher(self.data_train, self.device, depth=depth)
+            source = DevicePrefetcher(self.data_train, self.device, depth=depth, transform=self._host_batch_transform())
         if batches_to_skip:
             LOGGER.info(f"resume: epoch {epoch} starts at batch {batches_to_skip}")
         return itertools.islice(enumerate(source), batches_to_skip, self.geometry.usable_batches)
+
+    def _host_batch_transform(self):
+        """Right-padded batches lose their padding on the host, in the prefetch thread (``ssi.data.unpad``: exact, and the step's time then follows
+        the real tokens, not the padded rows).  ``padding_free: false`` in the config keeps the padded form; a
+        model without the packed path (stand-ins of the CPU tests) and callers that hand ``_train_step`` device tensors are not affected."""
+        if not self.cfg.get("padding_free", True) or not hasattr(self.model, "fused_loss") or not hasattr(self.model, "padded_seq_len"):
+            return None
+        from functools import partial
+
+        from .data.unpad import unpad_batch
+        tiles = getattr(self.model, "_mfma_shapes", lambda: False)()  # the MFMA kernels walk whole 256-row tiles; the generic ones take any length
+        return partial(unpad_batch, pad_id=self.tokenizer.pad_id, ignore_index=self.loss_fn.ignore_index, padded_len=self.model.padded_seq_len,
+                       multiple=256 if tiles else 1)
 
     def _train_epoch(self, epoch: int, batches_to_skip: int = 0) -> None:
         window = self.cfg.gradient_accumulation_steps
@@ -378,7 +393,8 @@ class Trainer:
             n_valid = (labels != ignore).sum()
         if hasattr(self.model, "sync_this_backward"):
             self.model.sync_this_backward = bool(sync_gradients)
-        loss_batch = compute_loss(batch, self.model, self.loss_fn) * n_valid  # mean over SHIFTED x UNSHIFTED count
+        self.unpadded_micro_batches += "packed_tokens" in batch  # (the prefetch thread dropped this batch's padding: ssi/data/unpad.py)
+        loss_batch = compute_loss(loss_inputs(batch), self.model, self.loss_fn) * n_valid  # mean over SHIFTED x UNSHIFTED count
         loss_batch.backward()
         if on_gpu:
             zero = torch.zeros(1, dtype=torch.float64, device=tokens.device)

@@ -268,25 +268,56 @@ def test_full_width_model_on_ragged_padded_micro_batches_matches_the_cpu_oracle(
     model.train()
     assert model._mfma_shapes() and model.padded_seq_len(3, 333) != 333
     n_total = 0
+    want_loss = []
     for b in batches:
         n = int((b["labels"] != -100).sum())
         n_total += n
         want = oracle_loss(b, ref, OracleCEWithChunkedOutputLoss())
         (want * n).backward()
-        got = compute_loss({k: v.to(DEV) for k, v in b.items()}, model, CEWithChunkedOutputLoss())
-        (got * n).backward()
-        rel = abs(got.item() - want.item()) / abs(want.item())
-        print(f"[ragged full-width] B x S = {tuple(b['tokens'].shape)}: loss {got.item():.6f} vs oracle {want.item():.6f} (rel {rel:.2e})")
-        assert rel <= 1e-2
+        want_loss.append(want.item())
+    # Round 4: the same micro-batches twice through the HIP model — as right-padded rows, and with the padding dropped on the host the way the
+    # trainer's prefetch thread does it (ssi/data/unpad.py: rows end to end as one packed sequence, block-causal attention, per-row positions).
+    # Both against the oracle on the PADDED batch, and against each other: the transform is exact, the two runs differ by the order of fp32
+    # sums inside the attention kernels and the bf16 rounding behind them.
+    from ssi.data import loss_inputs, unpad_batch
+    grads, losses = {}, {}
+    for how in ("padded", "unpadded"):
+        model.zero_grad(set_to_none=True)
+        losses[how] = []
+        for b, want in zip(batches, want_loss):
+            n = int((b["labels"] != -100).sum())
+            hb = b if how == "padded" else unpad_batch(b, pad_id=pad_id, padded_len=model.padded_seq_len)
+            assert ("packed_tokens" in hb) == (how == "unpadded")
+            if how == "unpadded":
+                assert hb["packed_tokens"].shape[1] < b["tokens"].shape[0] * model.padded_seq_len(*b["tokens"].shape)
+            got = compute_loss(loss_inputs({k: v.to(DEV) for k, v in hb.items()}), model, CEWithChunkedOutputLoss())
+            (got * n).backward()
+            rel = abs(got.item() - want) / abs(want)
+            print(f"[ragged full-width, {how}] B x S = {tuple(b['tokens'].shape)}: loss {got.item():.6f} vs oracle {want:.6f} (rel {rel:.2e})")
+            assert rel <= 1e-2
+            losses[how].append(got.item())
+        worst, worst_key = 0.0, None
+        for (k, p), (_, p2) in zip(model.named_parameters(), ref.named_parameters()):
+            err = float((p.grad.float().cpu() - p2.grad).norm() / p2.grad.norm())
+            if err > worst:
+                worst, worst_key = err, k
+            assert err <= TOL_GRAD_BF16, f"{how} {k}: relative gradient error {err}"
+        print(f"[ragged full-width, {how}] worst relative gradient error over two accumulated micro-batches {worst:.2e} ({worst_key}); {n_total} label tokens")
+        pad_rows = model._view("emb", None, model._flat_grad)[params["vocab_size"]:]
+        assert float(pad_rows.abs().max()) == 0.0      # the rows that pad the table to whole tiles never receive a gradient
+        grads[how] = {k: p.grad.float().cpu().clone() for k, p in model.named_parameters()}
+    for a, b_ in zip(losses["padded"], losses["unpadded"]):
+        # bf16 model: a row's attention outputs depend on where its keys fall in the 64-key tiles (fp32 sums in another order, then the bf16
+        # rounding): the two losses sit 6e-6 .. 9e-5 from the fp32 oracle, on either side of it.  In fp32 the transform is exact to 1e-6
+        # (tests/test_unpad.py, on the CPU oracle).
+        assert abs(a - b_) <= 1e-4 * abs(a), (a, b_)
     worst, worst_key = 0.0, None
-    for (k, p), (_, p2) in zip(model.named_parameters(), ref.named_parameters()):
-        err = float((p.grad.float().cpu() - p2.grad).norm() / p2.grad.norm())
+    for k in grads["padded"]:
+        err = float((grads["padded"][k] - grads["unpadded"][k]).norm() / grads["padded"][k].norm())
         if err > worst:
             worst, worst_key = err, k
-        assert err <= TOL_GRAD_BF16, f"{k}: relative gradient error {err}"
-    print(f"[ragged full-width] worst relative gradient error over two accumulated micro-batches {worst:.2e} ({worst_key}); {n_total} label tokens")
-    pad_rows = model._view("emb", None, model._flat_grad)[params["vocab_size"]:]
-    assert float(pad_rows.abs().max()) == 0.0      # the rows that pad the table to whole tiles never receive a gradient
+    print(f"[ragged full-width] padded vs unpadded: losses {losses}, worst relative gradient difference {worst:.2e} ({worst_key})")
+    assert worst <= 1e-2, (worst_key, worst)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -193,9 +193,12 @@ def test_returned_logits_are_not_overwritten_and_eval_between_forward_and_backwa
     assert torch.equal(model._flat_grad, want), "an eval forward between forward and backward changed the gradients"
 
 
+@pytest.mark.parametrize("ragged", [False, True], ids=["fixed-length", "ragged"])
 @pytest.mark.parametrize("dtype_name,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
-def test_trainer_three_steps_match_cpu_step_oracle(tmp_path, dtype_name, tol):
-    """End to end through Trainer.setup()/train() with synthetic MLS-shaped data, grad-accum 2, vs the CPU step oracle."""
+def test_trainer_three_steps_match_cpu_step_oracle(tmp_path, dtype_name, tol, ragged):
+    """End to end through Trainer.setup()/train() with synthetic MLS-shaped data, grad-accum 2, vs the CPU step oracle.  ``ragged``: rows of
+    unequal length, right-padded by the collate function as the reference does — the prefetch thread drops the padding (ssi/data/unpad.py)
+    and every micro-batch runs as one packed sequence, while the oracle steps through the PADDED batches."""
     import copy
     from oracle import step_oracle
     from oracle.llama_oracle import OracleCEWithChunkedOutputLoss, OracleLlama
@@ -208,6 +211,7 @@ def test_trainer_three_steps_match_cpu_step_oracle(tmp_path, dtype_name, tol):
         "tokenizer.max_seq_len=96", "data.train.dataset.n_samples=16", "data.dev.dataset.n_samples=4", "eval_steps=3", "save_steps=3",
         "lr_scheduler.num_warmup_steps=2", "optimizer.lr=1e-3", f"output_dir={tmp_path}", f"checkpointer.output_dir={tmp_path}/ckpt",
         f"checkpointer.checkpoint_dir={tmp_path}/none", "checkpointer.allow_random_init=true", "data.train.shuffle=false",
+        f"data.train.dataset.fixed_len={'false' if ragged else 'true'}",
     ])
     cfg.model_overrides = {"num_layers": 2, "num_heads": 4, "num_kv_heads": 2, "embed_dim": 64, "intermediate_dim": 128,
                            "max_seq_len": 256, "_base_vocab_size_txt": 300, "_n_special_txt": 16}
@@ -239,6 +243,11 @@ def test_trainer_three_steps_match_cpu_step_oracle(tmp_path, dtype_name, tol):
     batches = [{k: v.clone() for k, v in b.items()} for b in itertools_islice(t.data_train, 6)]
     t.train()
     assert t.global_step == 3 and len(t._loss_log) == 3 and t.consumed_samples == 3 * 2 * 2
+    if ragged:
+        assert any(int((b["labels"][r] != -100).sum()) < b["labels"].shape[1] - 8 for b in batches for r in range(2))
+        assert t.unpadded_micro_batches >= 4, t.unpadded_micro_batches
+    else:
+        assert t.unpadded_micro_batches == 0
     assert os.path.exists(tmp_path / "ckpt" / "step_3" / "model.safetensors") and os.path.exists(tmp_path / "ckpt" / "training_state.pt")
     rec = t.wandb_logger.records
     assert [r["step"] for r in rec] == [1, 2, 3] and "dev_loss" in rec[-1] and np.isfinite(rec[-1]["dev_loss"])
