@@ -494,7 +494,9 @@ def main() -> int:
         if sync is not None:  # what crossed xGMI and how much of it the step had to wait for (rank 0's view)
             out["comm"] = {"backend": dist.get_backend(), "library": "RCCL" if dist.get_backend() == "nccl" else dist.get_backend(),
                            "ranks": dist.get_world_size(), "allreduce_bytes_per_step": sync.bytes_reduced / args.steps,
-                           "buckets": len(sync.buckets), "exposed_ms_per_step": sync.exposed_ms() / args.steps}
+                           "buckets": len(sync.buckets), "exposed_ms_per_step": sync.exposed_ms() / args.steps,
+                           # per bucket: bytes, issue -> completion of its all-reduce, time the compute stream waited in front of it
+                           "per_bucket": sync.bucket_report(args.steps)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(42_831)

@@ -52,7 +52,12 @@ def restore_rng_states(state: dict[str, Any]) -> None:
     py = state["python"]
     random.setstate((py[0], tuple(py[1]), py[2]))  # lists -> tuples if a loader relaxed them
     # "numpy_global" with a tensor inside: files this package wrote before the key was renamed
-    kind, keys, pos, has_gauss, cached = state["numpy_global_tensors"] if "numpy_global_tensors" in state else state["numpy_global"]
+    entry = state.get("numpy_global_tensors", state.get("numpy_global"))
+    if entry is None or not torch.is_tensor(entry[1]):
+        raise RuntimeError("training state without a loadable NumPy generator state: neither `numpy_global_tensors` (this package) nor a "
+                           "tensor-valued `numpy_global` (its early builds); the reference stores the state as a NumPy array, which the "
+                           "restricted loader never unpickles (INTEGRATION.md, training-state compatibility)")
+    kind, keys, pos, has_gauss, cached = entry
     np.random.set_state((str(kind), keys.numpy().astype(np.uint32), int(pos), int(has_gauss), float(cached)))
     torch.set_rng_state(state["torch_cpu"])
     if "torch_cuda" in state and torch.cuda.is_available():

@@ -44,6 +44,9 @@ def init_distributed(device: torch.device, timeout_s: int = 600) -> tuple[int, i
     if world <= 1 and not _single_rank_exercise():
         return 1, 0
     if not dist.is_initialized():
+        if world <= 1 and not all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_PORT")):
+            raise RuntimeError("SSI_DP_SINGLE=1 runs the data-parallel exchange with one rank and still needs the launcher's environment "
+                               "(RANK, WORLD_SIZE, MASTER_PORT): start it under `python -m torch.distributed.run --nproc-per-node 1 ...`")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's peer mappings fail with the legacy mode on this driver
         backend = os.environ.get("SSI_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
@@ -52,7 +55,22 @@ def init_distributed(device: torch.device, timeout_s: int = 600) -> tuple[int, i
             torch.cuda.set_device(device)
             kwargs["device_id"] = device
         dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+        global _created_process_group
+        _created_process_group = True
     return dist.get_world_size(), dist.get_rank()
+
+
+_created_process_group = False  # set by init_distributed when IT called init_process_group (a group made by the caller is the caller's to destroy)
+
+
+def shutdown_distributed() -> None:
+    """Tear down what ``init_distributed`` created — at ANY world size (the one-rank RCCL exercise creates a group and a scalar
+    communicator too; left alive they leak into the next Trainer of the process and warn at exit)."""
+    global _created_process_group
+    if dist.is_available() and dist.is_initialized() and _created_process_group:
+        dist.barrier()
+        dist.destroy_process_group()
+    _created_process_group = False
 
 
 class GradSync:
@@ -64,6 +82,7 @@ class GradSync:
     def __init__(self, flat_grad: Tensor, buckets: list[tuple[str, int, int]], group=None):
         self.flat_grad, self.buckets, self.group = flat_grad, list(buckets), group
         self._pending: list = []
+        self._pending_names: list[str] = []
         self._done: set[str] = set()
         self._deferred = None          # ((work, done event), (lo, hi)) of the bucket finish(defer_last=True) left in flight
         self._last_range = (0, 0)
@@ -71,6 +90,10 @@ class GradSync:
         self.bytes_reduced = 0
         self.timing = False            # bench: time how long the compute stream sits waiting for reductions (exposed communication)
         self._wait_events: list = []
+        self._bucket_events: list = []  # (bucket, bytes, issue event, completion event) while `timing`
+        self._bucket_waits: list = []   # (bucket, event before / after the compute stream's wait for it) while `timing`
+        self._stream_ordered_wait = bool(flat_grad.is_cuda and dist.is_available() and dist.is_initialized()
+                                         and dist.get_backend(group) == "nccl")
         # token counts and the running loss travel on a communicator of their own: on the gradients' one they would queue behind
         # every bucket already issued (a communicator runs its collectives in issue order), the deferred embedding bucket included
         self.scalar_group = None
@@ -97,28 +120,45 @@ class GradSync:
         self._last_range = (lo, hi)
         buf = self.flat_grad[lo:hi]
         self.bytes_reduced += buf.numel() * buf.element_size()
+        t_issue = None
         if self._comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(buf.device))
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
+                if self.timing:  # bench: issue -> completion per bucket (which bucket is the exposed one on a multi-GPU node)
+                    t_issue = torch.cuda.Event(enable_timing=True)
+                    t_issue.record(self._comm_stream)
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self._stream_ordered_wait:
+                    # RCCL runs the collective on a stream of its own; a stream-level wait puts the SIDE stream behind it, so that the event
+                    # recorded next marks the collective's completion (gloo's wait would block the host here: its event marks the issue)
+                    work.wait()
+                done = self._record_done(buf.device, timed=self.timing)
         else:
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append((work, self._record_done(buf.device)))
+            done = None
+        if t_issue is not None:
+            self._bucket_events.append((name, buf.numel() * buf.element_size(), t_issue, done))
+        self._pending.append((work, done))
+        self._pending_names.append(name)
 
-    def _record_done(self, device):
-        """Event on the communication stream right behind the collective just issued: what the compute stream is made to wait for,
-        in addition to ``work.wait()`` — gloo's wait blocks the host and would hide a missing stream dependency, RCCL's only orders the
-        stream that is current when it is called."""
+    def _record_done(self, device, timed: bool = False):
+        """Event on the communication stream behind the collective just issued.  With RCCL (``_stream_ordered_wait``) the side stream has
+        been put behind the collective by a stream-level ``work.wait()``, so the event marks its COMPLETION; with gloo it marks the issue
+        (gloo's ``wait()`` blocks the host, it is called in ``_wait`` only).  Either way the compute stream's ordering also comes from
+        ``work.wait()`` in ``_wait``, which orders the stream that is CURRENT when it is called — ``_wait`` must run with the compute stream
+        current, never under the side stream."""
         if self._comm_stream is None:
             return None
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(enable_timing=timed)
         ev.record(self._comm_stream)
         return ev
 
     def _wait(self, item) -> None:
         work, done = item
+        if self._comm_stream is not None:  # work.wait() orders the CURRENT stream: it must be the compute stream, never the side stream
+            assert torch.cuda.current_stream(self.flat_grad.device) != self._comm_stream, "GradSync._wait under the communication stream"
         work.wait()
         if done is not None:
             torch.cuda.current_stream(self.flat_grad.device).wait_event(done)
@@ -135,11 +175,18 @@ class GradSync:
                 self.bucket_ready(name, lo, hi)
             if defer_last and len(self._pending) > 1:
                 self._deferred = (self._pending.pop(), self._last_range)
-            mark = self._mark()
-            for item in self._pending:  # every bucket but a deferred one: the compute stream waits for its completion event
+                self._deferred_name = self._pending_names.pop()
+            mark = first = self._mark()
+            for i, item in enumerate(self._pending):  # every bucket but a deferred one: the compute stream waits for its completion event
                 self._wait(item)
-            self._mark(mark)
+                if first is not None:  # timing: one more event per bucket = how long the compute stream sat in front of THIS bucket
+                    nxt = self._mark()
+                    self._bucket_waits.append((self._pending_names[i] if i < len(self._pending_names) else "?", mark, nxt))
+                    mark = nxt
+            if first is not None:
+                self._wait_events.append((first, mark))
         self._pending.clear()
+        self._pending_names.clear()
         self._done.clear()
 
     def deferred_range(self) -> Optional[tuple[int, int]]:
@@ -150,7 +197,9 @@ class GradSync:
         if self._deferred is not None:
             mark = self._mark()
             self._wait(self._deferred[0])
-            self._mark(mark)
+            end = self._mark(mark)
+            if end is not None:
+                self._bucket_waits.append((getattr(self, "_deferred_name", "?") + " (deferred)", mark, end))
             self._deferred = None
 
     def _mark(self, start=None):
@@ -169,6 +218,25 @@ class GradSync:
         total = sum(a.elapsed_time(b) for a, b in self._wait_events)
         self._wait_events.clear()
         return float(total)
+
+    def bucket_report(self, steps: int) -> list[dict]:
+        """Per bucket, averaged over ``steps`` timed steps (synchronise the device first): bytes, issue -> completion of its collective on
+        the side stream (RCCL; with gloo the completion event marks the issue and the figure is ~0), and the time the compute stream spent
+        waiting in front of it — the first multi-GPU run then says WHICH bucket is exposed without a second run."""
+        out: dict[str, dict] = {}
+        for name, nbytes, t0, t1 in self._bucket_events:
+            d = out.setdefault(name, {"bucket": name, "bytes": nbytes, "issue_to_done_ms": 0.0, "exposed_ms": 0.0})
+            if t1 is not None:
+                d["issue_to_done_ms"] += t0.elapsed_time(t1) / max(steps, 1)
+        for name, a, b in self._bucket_waits:
+            key = name.replace(" (deferred)", "")
+            d = out.setdefault(key, {"bucket": key, "bytes": None, "issue_to_done_ms": 0.0, "exposed_ms": 0.0})
+            d["exposed_ms"] += a.elapsed_time(b) / max(steps, 1)
+            if name.endswith("(deferred)"):
+                d["deferred"] = True
+        self._bucket_events.clear()
+        self._bucket_waits.clear()
+        return list(out.values())
 
     @classmethod
     def for_module(cls, module: torch.nn.Module, group=None) -> "ModuleGradSync":

@@ -465,8 +465,8 @@ class HipLlamaDecoder(nn.Module):
         H, KV, hd, dt, A = self.num_heads, self.num_kv_heads, self.head_dim, self.dtype, self._arena
         L = self.num_layers
         G = self._flat_grad
+        self._finish_pending_exchange()   # first: _window_accumulates() may zero slices of the buffer a deferred bucket is still reduced into
         acc = self._window_accumulates()  # False: first backward of the window, every gradient is written, not added
-        self._finish_pending_exchange()
         gv = lambda name: self._view(name, None, G)  # noqa: E731
         ws = A.get("ws.rms", (max(ops.rmsnorm_bwd_workspace_bytes(T, D), 16),), torch.uint8)
 
@@ -578,8 +578,8 @@ class HipLlamaDecoder(nn.Module):
     def _head_backward(self, dlogits: Tensor, hn: Tensor, alpha_dev: Optional[Tensor]) -> Tensor:
         """d_hn = alpha * dlogits @ E ;  dE += alpha * dlogits^T @ hn   (dlogits: [T, vocab_pad], pad columns zero)."""
         T, D = hn.shape
+        self._finish_pending_exchange()  # before anything may touch the gradient buffer (see _backward_hidden)
         acc = self._window_accumulates()
-        self._finish_pending_exchange()
         d_hn = self._arena.get("d_hn", (T, D), self.dtype)
         self._ensure_transposed()
         if self._has_t("emb"):

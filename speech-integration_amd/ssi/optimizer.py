@@ -87,6 +87,8 @@ class HipAdamW(torch.optim.Optimizer):
         # the gradients are NOT zeroed (2.5 GB of writes per step for nothing) and the window is NOT closed here: as with torch.optim, a
         # backward that follows a step without a zero_grad in between accumulates; zero_grad (this optimizer's, the model's, or a foreign
         # one that drops every p.grad) ends the window, and the first backward after it overwrites the buffer (model protocol)
+        if m.always_accumulate:  # SSI_ZERO_GRADS=1 (round-1 protocol): the kernel has just zeroed the buffer, a memset in zero_grad would do it twice
+            m._grads_dirty = m._grads_stale = False
         m._hip_epoch += 1  # weights changed behind torch's version counter
         if self._views_ready:
             for st in self.state.values():

@@ -531,7 +531,5 @@ class Trainer:
     def cleanup(self) -> None:
         if getattr(self, "wandb_logger", None) is not None:
             self.wandb_logger.close()
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and self.world_size and self.world_size > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        from .distributed import shutdown_distributed
+        shutdown_distributed()  # whatever init_distributed created, also the one-rank exercise's group (SSI_DP_SINGLE=1)
