@@ -1287,7 +1287,13 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
     const char* sel = getenv("SSI_ATTN_DKV");
     // (plain causal rows only: packed rows keep the 128-key kernel, whose waves skip the tiles outside their keys' documents — at B = 2,
     //  S = 8192 with documents of 440-1100 tokens the 256-key groups of this one, masking instead of skipping, took 409 us against 329)
-    const bool v2 = !doc_end && seq % 256 == 0 && rep % 4 == 0 && (seq / 32) * rep <= DKV2_MAX_STEPS && !(sel && sel[0] == '1');
+    // ... and only where its 256-key workgroups (one per CU at a time) can be balanced over the 256 CUs: the heaviest one walks (S / 32) * rep
+    // tiles, the chip's share per CU is the total over 256.  B = 8, S = 2048: 256 against 288; B = 2, S = 2048: 256 against 72 — there the
+    // 128-key kernel (two workgroups per CU, half the granularity) is faster.  SSI_ATTN_DKV=2 forces this kernel whatever the balance.
+    const int64_t ngrp2 = seq / 256, per0 = seq / 32;
+    const int64_t total_tiles = batch * n_kv * rep * (ngrp2 * per0 - 8 * ngrp2 * (ngrp2 - 1) / 2);
+    const bool balanced = per0 * rep * 256 <= total_tiles * 23 / 20 || (sel && sel[0] == '2');
+    const bool v2 = !doc_end && seq % 256 == 0 && rep % 4 == 0 && (seq / 32) * rep <= DKV2_MAX_STEPS && balanced && !(sel && sel[0] == '1');
     if (v2)
         hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3((unsigned)(batch * n_kv * (seq / 256))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
                            (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, rope, positions, (int)seq, n_heads, n_kv);

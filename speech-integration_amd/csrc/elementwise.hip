@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
                                                           const T* __restrict__ dres, T* __restrict__ dx,
                                                           float* __restrict__ partials, int64_t rows, int dim) {
     constexpr int N = Vec16<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][dim]
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][WS]
+    constexpr int WS = MAXV * N * 64;  // floats per wave in the staging buffer (>= dim)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = dim / N;
     float dw[MAXV][N];
@@ -183,17 +184,22 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
         fetch(row + 2 * wave_stride, q0);
         finish(row + wave_stride, q1);
     }
-    // block reduce of dscale partials
+    // block reduce of dscale partials.  Staged [wave][k][i][lane]: consecutive lanes on consecutive banks.  The column-major form
+    // [wave][column] (a lane's N consecutive floats = a 32-byte stride between lanes) was the one kernel of the step with LDS bank
+    // conflicts (SQ_LDS_BANK_CONFLICT 14.4 % of its LDS cycles, profiles/r03_pmc_kernels.md); same sums in the same order.
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
         const int v = lane + k * 64;
         if (v < nvec)
 #pragma unroll
-            for (int i = 0; i < N; ++i) lds[wave * dim + v * N + i] = dw[k][i];
+            for (int i = 0; i < N; ++i) lds[wave * WS + (k * N + i) * 64 + lane] = dw[k][i];
     }
     __syncthreads();
-    for (int c0 = threadIdx.x; c0 < dim; c0 += 256)
-        partials[(int64_t)blockIdx.x * dim + c0] = lds[c0] + lds[dim + c0] + lds[2 * dim + c0] + lds[3 * dim + c0];
+    for (int idx = threadIdx.x; idx < WS; idx += 256) {
+        const int l = idx & 63, ki = idx >> 6, v = l + (ki / N) * 64;
+        if (v < nvec)
+            partials[(int64_t)blockIdx.x * dim + v * N + ki % N] = lds[idx] + lds[WS + idx] + lds[2 * WS + idx] + lds[3 * WS + idx];
+    }
 }
 
 // dscale[c] += sum_b partials[b][c]   (fixed order -> deterministic).  64 columns x 16 row groups per 1024-thread block: every
@@ -260,6 +266,8 @@ template <typename T>
 static int launch_rmsnorm_bwd(const T* dy, const T* x, const T* scale, const float* rstd, const T* dres, T* dx, T* dscale,
                               int64_t rows, int dim, int nb, size_t lds_bytes, float* workspace, hipStream_t st, int accumulate) {
     const int64_t vec_per_lane = ssi_cdiv(dim / Vec16<T>::N, 64);
+    const int maxv = vec_per_lane <= 1 ? 1 : vec_per_lane <= 2 ? 2 : vec_per_lane <= 4 ? 4 : 8;
+    lds_bytes = (size_t)4 * maxv * Vec16<T>::N * 64 * sizeof(float);  // [4 waves][MAXV * N * 64]
     if (vec_per_lane <= 1)
         hipLaunchKernelGGL((rmsnorm_bwd_kernel<T, 1>), dim3(nb), dim3(256), lds_bytes, st, dy, x, scale, rstd, dres, dx, workspace, rows, dim);
     else if (vec_per_lane <= 2)
@@ -284,8 +292,8 @@ extern "C" int ssi_rmsnorm_bwd(const void* dy, const void* x, const void* scale,
         ssi_set_error("rmsnorm_bwd: workspace too small");
         return SSI_ERR_WORKSPACE;
     }
-    const size_t lds_bytes = 4 * dim * sizeof(float);
-    SSI_CHECK_ARG(lds_bytes <= 160 * 1024);
+    const size_t lds_bytes = 4 * ssi_align_up(dim, 512) * sizeof(float);  // upper bound of what launch_rmsnorm_bwd asks for
+    SSI_CHECK_ARG(dim <= 8 * 8 * 64 && 2 * lds_bytes <= 160 * 1024);
     int rc = SSI_OK;
     SSI_DISPATCH_DTYPE(dtype, rc = launch_rmsnorm_bwd<T>((const T*)dy, (const T*)x, (const T*)scale, rstd, (const T*)dres,
                                                          (T*)dx, (T*)dscale, rows, (int)dim, nb, lds_bytes,

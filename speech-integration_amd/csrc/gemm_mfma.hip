@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(NT4_THREADS, 1) void gemm_nt4dma_kernel(int tiles_m
 // partials (contiguous KiB reads), then the same rounding points and the same full-line stores as the direct epilogue:
 // C = (accumulate ? C : 0) + bf16(alpha * sum).
 __global__ __launch_bounds__(256) void nt4_splitk_reduce_kernel(const float* __restrict__ slabs, int splits, int tiles_m, int tiles_n,
-                                                                bf16_t* __restrict__ C, int64_t ldc, float alpha,
+                                                                bf16_t* __restrict__ C, int64_t ldc, const bf16_t* __restrict__ R, float alpha,
                                                                 const float* __restrict__ alpha_dev, int accumulate) {
     const int lane = threadIdx.x & 63;
     const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (tile, wave, i, jd)
@@ -1224,10 +1224,13 @@ __global__ __launch_bounds__(256) void nt4_splitk_reduce_kernel(const float* __r
     }
     const int lane_row = lane & 7, lane_col = ((lane >> 3) & 1) * 32 + (g & 1) * 16 + (g >> 1) * 8;
     bf16_t* base = C + ((int64_t)tm * BM + wm * NT4_WM + i * 16 + lane_row) * ldc + (int64_t)tn * BN + wn * NT4_WN + jd * 64 + lane_col;
+    // previous values (accumulate) or the residual (same rows, same leading dimension as C) are added to the ROUNDED product, as the
+    // unsplit epilogue does (F.linear then `+`: two roundings)
+    const int64_t r_off = R ? (R - C) : 0;
     auto finish = [&](u32x4 o, bf16_t* dst) {
-        if (accumulate) {
+        if (accumulate || R) {
             bf16x8 ob8 = __builtin_bit_cast(bf16x8, o);
-            const bf16x8 c = *reinterpret_cast<const bf16x8*>(dst);
+            const bf16x8 c = *reinterpret_cast<const bf16x8*>(dst + r_off);
 #pragma unroll
             for (int e = 0; e < 8; ++e) ob8[e] = (bf16_t)((float)ob8[e] + (float)c[e]);
             o = __builtin_bit_cast(u32x4, ob8);
@@ -1351,12 +1354,19 @@ int ssi_gemm_mfma_bf16_splitk(int layout, int64_t M, int64_t N, int64_t K, const
                               int accumulate, int splits, float* slabs, void* stream) {
     const int tm = (int)(M / BM), tn = (int)(N / BN);
     auto st = (hipStream_t)stream;
-    // weight-gradient form on the persistent kernel: units = tile x K-slice, every slice at least 6 K-steps, no residual
-    if (layout == SSI_GEMM_TN && nt4_ok(K) && nt4_ld_ok(lda, ldb) && !R && K / BK / splits >= 6 && ldc % 8 == 0) {
-        if (int rc = launch_nt4<true, true, EPI_PLAIN, 0, true, TN_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, nullptr, 1.f, nullptr, st,
-                                                                 EpiArgs{nullptr, 0, nullptr, 0, 0}, splits, slabs)) return rc;
+    // on the persistent kernel: units = tile x K-slice, every slice at least 6 K-steps.  Round 1-3: the weight-gradient form only; round 4: the
+    // k-contiguous (NT) and data-gradient (NN) forms too, for output grids that leave CUs idle at small batches (T = 4096: W_o, W2 forward and the
+    // data gradients of the N = 2048 projections have 128 tiles) or fill the last round badly (ragged T).  A residual is added by the reduction
+    // pass (not together with accumulate, like the unsplit form).
+    if (nt4_ok(K) && nt4_ld_ok(lda, ldb) && !(R && accumulate) && K / BK / splits >= 6 && ldc % 8 == 0) {
+        const EpiArgs none{nullptr, 0, nullptr, 0, 0};
+        int rc = SSI_ERR_ARG;
+        if (layout == SSI_GEMM_TN) rc = launch_nt4<true, true, EPI_PLAIN, 0, true, TN_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, nullptr, 1.f, nullptr, st, none, splits, slabs);
+        else if (layout == SSI_GEMM_NT) rc = launch_nt4<false, false, EPI_PLAIN, 0, true, NT_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, nullptr, 1.f, nullptr, st, none, splits, slabs);
+        else if (layout == SSI_GEMM_NN) rc = launch_nt4<false, true, EPI_PLAIN, 0, true, NN_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, nullptr, 1.f, nullptr, st, none, splits, slabs);
+        if (rc) return rc;
         hipLaunchKernelGGL(nt4_splitk_reduce_kernel, dim3((unsigned)ssi_cdiv((int64_t)tm * tn * 64, 4)), dim3(256), 0, st, slabs, splits, tm, tn,
-                           (bf16_t*)C, ldc, alpha, alpha_dev, accumulate);
+                           (bf16_t*)C, ldc, (const bf16_t*)R, alpha, alpha_dev, accumulate);
         SSI_LAUNCH_CHECK();
         return SSI_OK;
     }

@@ -400,6 +400,23 @@ class HipLlamaDecoder(nn.Module):
         as32 = lambda t: t.to(torch.int32).reshape(-1).contiguous()  # noqa: E731
         return as32(input_pos if max_pos is None else input_pos.clamp(max=max_pos)), as32(doc_start), as32(doc_end)
 
+    # SSI_SPLITK_NT=0 (A/B runs): keep the k-contiguous / data-gradient GEMMs unsplit whatever their output grid
+    split_small_grids = os.environ.get("SSI_SPLITK_NT", "1") != "0"
+
+    def _gemm(self, layout: int, a: Tensor, b: Tensor, c: Tensor, residual: Optional[Tensor] = None) -> None:
+        """``ops.gemm`` for the forward projections and the data gradients, with K split where the 256 x 256 output grid leaves CUs idle:
+        at the reference's default micro-batches (``conf/data/_sft_base.yaml:21``: 2 x 2048 = 4096 rows) W_o, W2 and the data gradients of
+        the N = 2048 projections have 128 tiles for 256 CUs, and a ragged packed length fills its last round badly.  ``ops.splitk_choice``
+        weighs the halved rounds against the fp32 partial tiles' traffic (K = 2048: a draw; K = 8192 / 16 384: 1.6-1.8 x)."""
+        M, N = c.shape
+        K = a.shape[1]
+        splits = ops.splitk_choice(M, N, K) if (self.split_small_grids and self.dtype == torch.bfloat16 and self._mfma_shapes()) else 1
+        if splits > 1:
+            wsk = self._arena.get("ws.splitk.nt", (splits * M * N,), torch.float32)
+            ops.gemm_splitk(layout, a, b, c, splits, wsk, residual=residual)
+        else:
+            ops.gemm(layout, a, b, c, residual=residual)
+
     def _forward_hidden(self, tokens: Tensor, save: bool, input_pos: Optional[Tensor] = None) -> Tensor:
         B, S = tokens.shape
         pos = ds = de = None
@@ -434,7 +451,7 @@ class HipLlamaDecoder(nn.Module):
             lse = A.get(f"lse.{sfx}", (B * H * S,), torch.float32)
             ops.attn_fwd(qkv, att, lse, B, S, H, KV, hd, ds, de)
             hmid = A.get(f"hmid.{sfx}", (T, D), dt)
-            ops.gemm(GEMM_NT, att, self._view(f"L{l}.wo"), hmid, residual=h)
+            self._gemm(GEMM_NT, att, self._view(f"L{l}.wo"), hmid, residual=h)
             xn2 = A.get(f"xn2.{sfx}", (T, D), dt)
             rstd2 = A.get(f"rstd2.{sfx}", (T,), torch.float32)
             ops.rmsnorm_fwd(hmid, self._view(f"L{l}.mlp_norm"), xn2, rstd2, self.norm_eps)
@@ -443,7 +460,7 @@ class HipLlamaDecoder(nn.Module):
             ops.gemm_swiglu_fwd(xn2, self._view(f"L{l}.w13"), gu, act)  # SwiGLU rides in the GEMM epilogue
             hn_name = f"h{l + 1}" if save else f"hx{l & 1}"
             hnext = A.get(hn_name, (T, D), dt)
-            ops.gemm(GEMM_NT, act, self._view(f"L{l}.w2"), hnext, residual=hmid)
+            self._gemm(GEMM_NT, act, self._view(f"L{l}.w2"), hnext, residual=hmid)
             h = hnext
         hn = A.get("hn" if save else "hn.x", (T, D), dt)
         rstdf = A.get("rstdf" if save else "rstdf.x", (T,), torch.float32)
@@ -508,9 +525,9 @@ class HipLlamaDecoder(nn.Module):
         def dgrad(dy: Tensor, name: str, dx: Tensor) -> None:
             """dx = dy @ W  (W = [out, in]); NT form on the [in, out] copy where one is kept."""
             if self._has_t(name):
-                ops.gemm(GEMM_NT, dy, self._view_t(name), dx)
+                self._gemm(GEMM_NT, dy, self._view_t(name), dx)
             else:
-                ops.gemm(GEMM_NN, dy, self._view(name), dx)
+                self._gemm(GEMM_NN, dy, self._view(name), dx)
 
         dh = A.get("dh.a", (T, D), dt)
         ops.rmsnorm_bwd(d_hn, A.get(f"h{L}", (T, D), dt), self.norm.scale, A.get("rstdf", (T,), torch.float32), None, dh,

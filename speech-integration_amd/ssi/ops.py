@@ -196,8 +196,8 @@ def splitk_choice(M: int, N: int, K: int, n_cu: int = 256) -> int:
     if M % 256 or N % 256 or K % 64:
         return 1
     tiles, nk = (M // 256) * (N // 256), K // 64
-    if tiles >= n_cu:
-        return 1
+    if tiles >= 4 * n_cu or tiles % n_cu == 0:
+        return 1  # whole rounds, or so many rounds that the partial last one is a small share
     best, best_t = 1, None
     for s in (1, 2, 3, 4, 6, 8, 12, 16):
         if s > nk:
@@ -210,13 +210,15 @@ def splitk_choice(M: int, N: int, K: int, n_cu: int = 256) -> int:
 
 
 def gemm_splitk(layout: int, a: Tensor, b: Tensor, c: Tensor, splits: int, workspace: Tensor, *, alpha: float = 1.0,
-                alpha_dev: Tensor | None = None, accumulate: bool = False) -> None:
+                alpha_dev: Tensor | None = None, accumulate: bool = False, residual: Tensor | None = None) -> None:
     if splits <= 1:
-        return gemm(layout, a, b, c, alpha=alpha, alpha_dev=alpha_dev, accumulate=accumulate)
+        return gemm(layout, a, b, c, alpha=alpha, alpha_dev=alpha_dev, accumulate=accumulate, residual=residual)
     M, N = c.shape
     K = a.shape[1] if layout in (GEMM_NT, GEMM_NN) else a.shape[0]
     assert a.stride(1) == 1 and b.stride(1) == 1 and c.stride(1) == 1 and a.dtype == b.dtype == c.dtype
-    check(_lib.load().ssi_gemm_splitk(layout, M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(c), c.stride(0), None,
+    if residual is not None:
+        assert residual.shape == c.shape and residual.stride() == c.stride() and residual.dtype == c.dtype and not accumulate
+    check(_lib.load().ssi_gemm_splitk(layout, M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(c), c.stride(0), ptr(residual),
                                       alpha, ptr(alpha_dev), int(accumulate), dtype_code(c.dtype), splits, ptr(workspace),
                                       workspace.numel() * workspace.element_size(), stream_ptr()), "ssi_gemm_splitk")
 

@@ -32,7 +32,7 @@ def bwd(sel):
     ops.attn_bwd(qkv, out, dout, lse, d, delta, B, S, H, KV, hd, **kw)
     torch.cuda.synchronize()
     return d
-old, new, new2 = bwd('1'), bwd('0'), bwd('0')
+old, new, new2 = bwd('1'), bwd('2'), bwd('2')
 kv = slice(H * hd, None)
 print('reproducible:', bool((new == new2).all()), ' q block identical:', bool((old[:, :H * hd] == new[:, :H * hd]).all()))
 a, b_ = old[:, kv].float(), new[:, kv].float()
@@ -49,9 +49,9 @@ def t(sel, iters=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
 for rep in range(3):
-    print(f'bwd (dQ + dK/dV) us: old {t("1"):.0f}  new {t("0"):.0f}', flush=True)
+    print(f'bwd (dQ + dK/dV) us: old {t("1"):.0f}  new {t("2"):.0f}  default {t("0"):.0f}', flush=True)
 if 'stamps' in sys.argv:  # SSI_HIP_LIB = a -DDKV2_STAMP build (tools/variant.sh stamp2 attention_mfma.hip -DDKV2_STAMP)
-    d = bwd('0')
+    d = bwd('2')
     names = ['A.dkv (sync tile)', 'A.sp+barrier+tr', 'B.dkv+rows', 'B.sp+dma', 'A.dkv (plain tile)', 'A.sp+tr', 'B.dkv+rows', 'B.sp']
     for g in range(S // 256):
         v = d[g * 256].view(torch.float32)[:11].tolist()  # batch 0, kv head 0
