@@ -331,6 +331,9 @@ def main() -> int:
     ap.add_argument("--padded", action="store_true",
                     help="secondary workload (SURVEY.md §8d): sequence lengths ~U(0.4 S, S), right-padded to the batch maximum; "
                          "tokens/s then counts NON-PAD tokens.  Not the headline line.")
+    ap.add_argument("--grad-accum", type=int, default=1,
+                    help="micro-batches per optimizer step (the headline line uses 1, the most conservative reading; the reference's default is 4, "
+                         "conf/training.yaml:11): a step is then grad-accum forward + backward passes and one AdamW pass.  Not the headline line.")
     ap.add_argument("--no-unpad", action="store_true",
                     help="with --padded: run the right-padded rows as they are (the round-1..3 behaviour) instead of dropping the padding on the "
                          "host as the trainer's prefetch thread does (ssi/data/unpad.py)")
@@ -406,13 +409,18 @@ def main() -> int:
     if not args.no_gemm_timing and rank == 0:
         timer.install()
 
+    ga = max(1, args.grad_accum)
+
     def one_step(i: int) -> tuple[float, int]:
-        b = batches[i % len(batches)]
-        counts = count_token_types_async(b["tokens"], ranges, pad_id, b["labels"], -100)
-        model.sync_this_backward = True
-        loss_batch = compute_loss(loss_inputs(b) if not args.packed else b, model, loss_fn) * counts[-1]
-        loss_batch.backward()
-        host = torch.cat((counts.double(), loss_batch.detach().double().reshape(1))).tolist()  # the step's one D2H sync
+        rows = []
+        for j in range(ga):  # the accumulation window: only its last backward exchanges gradients; counts and losses stay on the device
+            b = batches[(i * ga + j) % len(batches)]
+            counts = count_token_types_async(b["tokens"], ranges, pad_id, b["labels"], -100)
+            model.sync_this_backward = j == ga - 1
+            loss_batch = compute_loss(loss_inputs(b) if not args.packed else b, model, loss_fn) * counts[-1]
+            loss_batch.backward()
+            rows.append(torch.cat((counts.double(), loss_batch.detach().double().reshape(1))))
+        host = torch.stack(rows).sum(0).tolist()  # the step's one D2H sync
         n_tok, loss_run = int(host[-2]), host[-1]
         if sync is not None:
             n_tok, loss_run = (lambda v: (int(round(v[0])), v[1]))(all_reduce_scalars([n_tok, loss_run], device, group=sync.scalar_group))
@@ -445,9 +453,10 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    tokens_per_step = args.batch * args.seq * world
+    tokens_per_step = args.batch * args.seq * world * ga
     if args.padded:  # non-pad tokens actually processed in the timed steps (all ranks draw the same length distribution)
-        tokens_per_step = world * sum(int((batches[(args.warmup + i) % len(batches)]["tokens"] != pad_id).sum()) for i in range(args.steps)) / args.steps
+        tokens_per_step = world * sum(int((batches[((args.warmup + i) * ga + j) % len(batches)]["tokens"] != pad_id).sum())
+                                      for i in range(args.steps) for j in range(ga)) / args.steps
     value = tokens_per_step * args.steps / elapsed
     f_tok = flops_per_token(lcfg.vocab_size, args.seq, layers=args.layers) if args.layers == 16 else None
     if args.packed and f_tok:  # attention term over the documents instead of the whole row
@@ -463,11 +472,11 @@ def main() -> int:
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"Llama-3.2-1B +{args.n_dsus} DSUs (V={lcfg.vocab_size}), SFT step fwd+bwd+AdamW, seq_len={args.seq}, "
-                                   f"batch={args.batch}/GPU, grad_accum=1, {args.layers} layers, random-init weights, MLS-shaped synthetic DSU sequences"
+                                   f"batch={args.batch}/GPU, grad_accum={ga}, {args.layers} layers, random-init weights, MLS-shaped synthetic DSU sequences"
                                    + (", rows packed with 440-1100-token documents (block-causal attention)" if args.packed else "")
                                    + (", lengths ~U(0.4 S, S) right-padded, non-pad tokens counted" if args.padded else "")
                                    + (", padding dropped on the host (ssi/data/unpad.py)" if args.padded and not args.no_unpad else ""),
-                       "global_batch": args.batch * world, "seq_len": args.seq, "parallelism": f"dp{world}", "last_loss": loss},
+                       "global_batch": args.batch * world * ga, "seq_len": args.seq, "parallelism": f"dp{world}", "last_loss": loss},
         }
         if f_tok:
             out["mfma_roofline_frac_step"] = value * f_tok / (world * MFMA_PEAK_TFLOPS * 1e12)

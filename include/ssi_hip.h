@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define SSI_ABI_VERSION 5 /* 5: ssi_doc_ranges takes n_clamped (out-of-table positions are counted, not only clamped)
+#define SSI_ABI_VERSION 6 /* 6: + ssi_attn_bwd_workspace_bytes, ssi_attn_varlen_bwd_ws (attention backward with a caller-owned workspace)
+                           * 5: ssi_doc_ranges takes n_clamped (out-of-table positions are counted, not only clamped)
                            * 4: + ssi_gemm_batched
                            * 2: + ssi_attn_varlen_fwd/bwd(_rope), ssi_set_gemm_tile_order, NN form of ssi_gemm_swiglu_bwd
                            * 3: ssi_ce_reduce takes `vocab` and reports out-of-range labels in out[3]; + ssi_doc_ranges; ssi_rmsnorm_bwd takes accumulate_dscale; + ssi_lmhead_ce_fwd/bwd */
@@ -128,6 +129,17 @@ int ssi_attn_varlen_bwd_rope(const void* qkv, int64_t ld, const void* out, const
                              float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope_table,
                              int64_t table_len, const int32_t* positions, int64_t batch, int64_t seq, int n_heads, int n_kv,
                              int head_dim, int dtype, void* stream);
+
+/* The same backward with a caller-owned workspace (any of the forms above: doc_start / doc_end and rope_table may be NULL).
+ * ssi_attn_bwd_workspace_bytes: what this shape can use, 0 = nothing.  With at least that many bytes (16-byte aligned), launches whose
+ * workgroups cannot fill the chip — the reference's default micro-batch of 2 x 2048 rows gives dK / dV 256 workgroups, the heaviest as long as
+ * the launch — run dK / dV as one workgroup per query head with fp32 partial rows in the workspace and a reduction over the heads in fixed
+ * order (reproducible; the sums over the heads are taken in another order than without workspace). */
+int64_t ssi_attn_bwd_workspace_bytes(int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype);
+int ssi_attn_varlen_bwd_ws(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
+                           float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope_table,
+                           int64_t table_len, const int32_t* positions, int64_t batch, int64_t seq, int n_heads, int n_kv,
+                           int head_dim, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- K7  SwiGLU elementwise (torchtune FeedForward: w2(silu(w1 x) * w3 x)) ------------------------------------------ */
 /* gu: [rows, 2*inter] = [gate | up]; act[rows, inter] = silu(gate) * up */

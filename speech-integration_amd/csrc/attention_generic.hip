@@ -14,7 +14,8 @@ int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, const 
                       int n_heads, int n_kv, void* stream);
 int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
                       float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope, const int32_t* positions,
-                      int64_t batch, int64_t seq, int n_heads, int n_kv, void* stream);
+                      int64_t batch, int64_t seq, int n_heads, int n_kv, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t ssi_attn_mfma_bwd_workspace_bytes(int64_t batch, int64_t seq, int n_heads, int n_kv);
 extern "C" int ssi_rope_inplace(void* x, int64_t ld, int64_t rows, int64_t seq_len, int n_heads_rot, int head_dim, const float* table,
                                 int64_t table_len, const int32_t* positions, int inverse, int dtype, void* stream);
 
@@ -237,7 +238,7 @@ extern "C" int ssi_attn_varlen_fwd(const void* qkv, int64_t ld, void* out, float
 static int attn_varlen_bwd_impl(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
                                 float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope_table,
                                 int64_t table_len, const int32_t* positions, int64_t batch, int64_t seq, int n_heads, int n_kv,
-                                int head_dim, int dtype, void* stream) {
+                                int head_dim, int dtype, void* stream, void* workspace = nullptr, int64_t workspace_bytes = 0) {
     if (int rc = attn_check(qkv, ld, batch, seq, n_heads, n_kv, head_dim)) return rc;
     SSI_CHECK_ARG(out && dout && lse && dqkv && delta && ((doc_start == nullptr) == (doc_end == nullptr)));
     if (batch * seq == 0) return SSI_OK;
@@ -245,7 +246,7 @@ static int attn_varlen_bwd_impl(const void* qkv, int64_t ld, const void* out, co
     if ((ssi_get_impl() == SSI_IMPL_MFMA || ssi_get_impl() == SSI_IMPL_MFMA_WG8) && !fast) { ssi_set_error("ssi_attn_bwd: MFMA path forced but unsupported shape"); return SSI_ERR_UNSUPPORTED; }
     if (fast && ssi_get_impl() != SSI_IMPL_GENERIC)
         return ssi_attn_bwd_mfma(qkv, ld, out, dout, lse, dqkv, delta, doc_start, doc_end, rope_table, positions, batch, seq, n_heads, n_kv,
-                                 stream);
+                                 workspace, workspace_bytes, stream);
     auto st = (hipStream_t)stream;
     const int64_t nq = batch * n_heads * seq, nk = batch * n_kv * seq;
     SSI_DISPATCH_DTYPE(dtype, ATTN_HD_SWITCH(head_dim, {
@@ -280,6 +281,25 @@ extern "C" int ssi_attn_varlen_bwd_rope(const void* qkv, int64_t ld, const void*
                                 n_heads, n_kv, head_dim, dtype, stream);
 }
 
+
+/* ABI v6: the backward with a caller-owned workspace.  ssi_attn_bwd_workspace_bytes says how much this shape can use (0: none); with at least
+ * that much, launches whose workgroups cannot fill the chip (small batches) run dK / dV as one workgroup per query head plus a reduction over the
+ * heads.  rope_table may be NULL (then dqkv stays in post-RoPE space, as ssi_attn_varlen_bwd).  Without workspace: ssi_attn_varlen_bwd(_rope). */
+extern "C" int64_t ssi_attn_bwd_workspace_bytes(int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype) {
+    if (batch <= 0 || seq <= 0 || n_heads <= 0 || n_kv <= 0 || n_heads % n_kv) return 0;
+    if (!ssi_attn_mfma_supported(8, batch, seq, n_heads, n_kv, head_dim, dtype) || ssi_get_impl() == SSI_IMPL_GENERIC) return 0;
+    return ssi_attn_mfma_bwd_workspace_bytes(batch, seq, n_heads, n_kv);
+}
+
+extern "C" int ssi_attn_varlen_bwd_ws(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
+                                      float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope_table,
+                                      int64_t table_len, const int32_t* positions, int64_t batch, int64_t seq, int n_heads, int n_kv,
+                                      int head_dim, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+    SSI_CHECK_ARG(!rope_table || positions != nullptr || table_len >= seq);
+    SSI_CHECK_ARG(workspace_bytes >= 0 && (workspace != nullptr || workspace_bytes == 0));
+    return attn_varlen_bwd_impl(qkv, ld, out, dout, lse, dqkv, delta, doc_start, doc_end, rope_table, table_len, positions, batch, seq,
+                                n_heads, n_kv, head_dim, dtype, stream, workspace, workspace_bytes);
+}
 
 extern "C" int ssi_attn_fwd(const void* qkv, int64_t ld, void* out, float* lse, int64_t batch, int64_t seq, int n_heads,
                             int n_kv, int head_dim, int dtype, void* stream) {

@@ -598,21 +598,35 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_bwd_dq_kernel
 // buffered, one step ahead), so Q and dO cross the L2 -> CU path once per 128 keys instead of once per 32, and the sum
 // over the query heads of the group happens in registers: no cross-wave reduction, no partial buffers, one writer per
 // output element.
+// HSPLIT (round 4): one workgroup per QUERY HEAD of the group instead of one for all `rep` of them; its dK / dV sums leave as fp32 partial
+// rows in `partial` ([head of the group][B * S][KV][dK 64 | dV 64]) and attn_dkv_head_reduce_kernel adds the heads in a fixed order.  For
+// launches whose workgroups cannot fill the chip: the longest workgroup IS the launch (B = 2, S = 2048: 256 workgroups, the heaviest with
+// 256 steps: 176 us per layer where 65 is the launch's share of the chip), and a workgroup's steps are queries x heads.
+template <bool HSPLIT>
 __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
                                                            const int32_t* __restrict__ doc_end, const float* __restrict__ rope,
-                                                           const int32_t* __restrict__ positions, int S, int H, int KV) {
+                                                           const int32_t* __restrict__ positions, int S, int H, int KV,
+                                                           float* __restrict__ partial) {
     // ring of RING step buffers: [Q tile 4 KiB | dO tile 4 KiB | lse 128 B | delta 128 B]; requests run RING-1 steps ahead
     constexpr int SB = 8192 + 256;
     constexpr int RING = DKV_RING;
     __shared__ __attribute__((aligned(16))) char smem[RING * SB];
     TRACE_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rep = H / KV;
+    const int rep_all = H / KV;
+    const int rep = HSPLIT ? 1 : rep_all;  // query heads this workgroup sweeps
     const int ngrp = S / 128;
-    int kgrp, pair_;  // low key groups (most work) are dispatched first
-    block_to_work(ngrp, (int)(gridDim.x / ngrp), kgrp, pair_);
+    int kgrp, pair_, head0 = 0;  // low key groups (most work) are dispatched first
+    if (HSPLIT) {
+        int r;
+        block_to_work(ngrp * rep_all, (int)(gridDim.x / (ngrp * rep_all)), r, pair_);
+        kgrp = r / rep_all;
+        head0 = r % rep_all;
+    } else {
+        block_to_work(ngrp, (int)(gridDim.x / ngrp), kgrp, pair_);
+    }
     const int kvh = pair_ % KV;
     const int b = pair_ / KV;
     const int h = lane >> 5;
@@ -655,11 +669,11 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
     // 64-bit address arithmetic cost 67 scalar instructions per step and wave before (SQ_INSTS_SALU), a fifth of the step's issue
     int iss_qt = 0;                                  // query tile of the next request inside its head
     const int irow = wave * 8 + (lane >> 3), ichunk = (lane & 7) ^ swz<SWZ_DUAL>(wave * 8 + (lane >> 3));
-    const u32x4 rs_q = buffer_rsrc(qkv + row0 * ld + (int64_t)kvh * rep * HD);    // Q columns of the group's first head, this batch
-    const u32x4 rs_do = buffer_rsrc(dout + row0 * ldo + (int64_t)kvh * rep * HD);
+    const u32x4 rs_q = buffer_rsrc(qkv + row0 * ld + (int64_t)(kvh * rep_all + head0) * HD);    // Q columns of the group's first head, this batch
+    const u32x4 rs_do = buffer_rsrc(dout + row0 * ldo + (int64_t)(kvh * rep_all + head0) * HD);
     const unsigned voff_q = (unsigned)((irow * ld + ichunk * 8) * 2), voff_do = (unsigned)((irow * ldo + ichunk * 8) * 2);
     unsigned soff_q = (unsigned)(qb_first * 32 * ld * 2), soff_do = (unsigned)(qb_first * 32 * ldo * 2);  // scalar, advanced per request
-    const float* iss_rc = (lane < 32 ? lse : delta) + ((int64_t)b * H + kvh * rep) * S + qb_first * 32 + (lane & 31);
+    const float* iss_rc = (lane < 32 ? lse : delta) + ((int64_t)b * H + kvh * rep_all + head0) * S + qb_first * 32 + (lane & 31);
     const unsigned lds_piece = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)smem + (unsigned)wave * 1024u);
     const unsigned lds_rc = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)smem + 8192u);
     auto issue = [&](int step) {
@@ -811,6 +825,22 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
         dbg[8] = (float)n_steps;
     }
 #endif
+    if constexpr (HSPLIT) {  // raw fp32 sums of this head: [head][row][kv head][dK 64 | dV 64]; scale, RoPE backward and rounding happen after the heads are added
+        const int64_t t_rows = (int64_t)(gridDim.x / (ngrp * rep_all)) / KV * S;  // B * S
+        float* prow = partial + (((int64_t)head0 * t_rows + row0 + kg) * KV + kvh) * 128;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 vk, vv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vk[e] = dk[db][4 * g + e]; vv[e] = dv[db][4 * g + e]; }
+                *reinterpret_cast<f32x4*>(prow + db * 32 + 8 * g + 4 * h) = vk;
+                *reinterpret_cast<f32x4*>(prow + 64 + db * 32 + 8 * g + 4 * h) = vv;
+            }
+        TRACE_END(2, n_steps);
+        return;
+    }
     // lane = key, registers = d (runs of 4): 8-byte stores into the k and v column blocks of dqkv
     bf16_t* krow_out = dqkv + (row0 + kg) * ld + (int64_t)H * HD + (int64_t)kvh * HD;
     bf16_t* vrow_out = krow_out + (int64_t)KV * HD;
@@ -1253,6 +1283,43 @@ extern "C" int ssi_debug_attn_trace(void* dst_host, int kernel) {  // debug buil
 }
 #endif
 
+// Adds the per-head partial rows of the HSPLIT form in head order (fixed: reproducible), then does what the unsplit kernel's epilogue does:
+// dK * -2^-3 (the sums carry the opposite sign), optional RoPE backward, rounding, stores.  One thread per (row, kv head, 4 columns).
+__global__ __launch_bounds__(256) void attn_dkv_head_reduce_kernel(const float* __restrict__ partial, int rep, int64_t t_rows, int KV,
+                                                                   bf16_t* __restrict__ dqkv, int64_t ld, int H, const float* __restrict__ rope,
+                                                                   const int32_t* __restrict__ positions, int S) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (row, kvh, c4) with c4 = 0..31: dK columns 4 c4 .. (c4 < 16), dV columns (c4 - 16) * 4 ..
+    if (i >= t_rows * KV * 32) return;
+    const int c4 = (int)(i & 31), kvh = (int)((i >> 5) % KV);
+    const int64_t row = (i >> 5) / KV;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int hd = 0; hd < rep; ++hd) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (((int64_t)hd * t_rows + row) * KV + kvh) * 128 + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum[e] += v[e];
+    }
+    bf16x4 o;
+    bf16_t* dst;
+    if (c4 < 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(sum[e] * -0.125f);
+        if (rope) o = unrope4(o, rope + (int64_t)(positions ? positions[row] : (int)(row % S)) * HD, c4 * 4);
+        dst = dqkv + row * ld + (int64_t)H * HD + (int64_t)kvh * HD + c4 * 4;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)sum[e];
+        dst = dqkv + row * ld + (int64_t)(H + KV) * HD + (int64_t)kvh * HD + (c4 - 16) * 4;
+    }
+    *reinterpret_cast<bf16x4*>(dst) = o;
+}
+
+// fp32 workspace the head-split dK / dV form wants for this shape (0: the launch fills the chip without it, or a single head per kv head)
+int64_t ssi_attn_mfma_bwd_workspace_bytes(int64_t batch, int64_t seq, int n_heads, int n_kv) {
+    const int rep = n_heads / n_kv;
+    if (rep <= 1 || seq % 128 || batch * n_kv * (seq / 128) >= 2 * 256) return 0;  // two workgroups per CU: 512 of them fill the chip
+    return (int64_t)rep * batch * seq * n_kv * 128 * (int64_t)sizeof(float);
+}
+
 bool ssi_attn_mfma_supported(int64_t ld, int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype) {
     if (dtype != SSI_BF16 || head_dim != HD) return false;
     const int rep = n_heads / n_kv;
@@ -1276,7 +1343,7 @@ int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, const 
 
 int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
                       const int32_t* doc_start, const int32_t* doc_end, const float* rope, const int32_t* positions, int64_t batch,
-                      int64_t seq, int n_heads, int n_kv, void* stream) {
+                      int64_t seq, int n_heads, int n_kv, void* workspace, int64_t workspace_bytes, void* stream) {
     auto st = (hipStream_t)stream;
     const int rep = n_heads / n_kv, qpw = ANW / rep;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * n_kv * (seq / (32 * qpw)))), dim3(64 * ANW), 0, st, (const bf16_t*)qkv,
@@ -1297,9 +1364,20 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
     if (v2)
         hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3((unsigned)(batch * n_kv * (seq / 256))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
                            (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, rope, positions, (int)seq, n_heads, n_kv);
-    else
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(batch * n_kv * (seq / 128))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
-                           (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, rope, positions, (int)seq, n_heads, n_kv);
+    else {
+        // small launches: one workgroup per query head + a reduction, when the caller brought the workspace (SSI_ATTN_DKV=3: never)
+        const int64_t want = ssi_attn_mfma_bwd_workspace_bytes(batch, seq, n_heads, n_kv);
+        if (want > 0 && workspace && workspace_bytes >= want && ((uintptr_t)workspace & 15) == 0 && !(sel && sel[0] == '3')) {
+            hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3((unsigned)(batch * n_kv * (seq / 128) * rep)), dim3(256), 0, st, (const bf16_t*)qkv, ld,
+                               (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, rope, positions, (int)seq, n_heads, n_kv, (float*)workspace);
+            SSI_LAUNCH_CHECK();
+            hipLaunchKernelGGL(attn_dkv_head_reduce_kernel, dim3((unsigned)ssi_cdiv(batch * seq * n_kv * 32, 256)), dim3(256), 0, st,
+                               (const float*)workspace, rep, batch * seq, n_kv, (bf16_t*)dqkv, ld, n_heads, rope, positions, (int)seq);
+        } else {
+            hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3((unsigned)(batch * n_kv * (seq / 128))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
+                               (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, rope, positions, (int)seq, n_heads, n_kv, (float*)nullptr);
+        }
+    }
     SSI_LAUNCH_CHECK();
     return SSI_OK;
 }

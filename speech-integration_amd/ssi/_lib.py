@@ -20,7 +20,7 @@ SSI_F32, SSI_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_MFMA_WG8 = 0, 1, 2, 3
 TILES_STATIC, TILES_DYNAMIC = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # name -> (restype, argtypes); mirrors include/ssi_hip.h line by line
 _P = c_void_p
@@ -44,6 +44,9 @@ PROTOTYPES = {
     "ssi_attn_varlen_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_int, _P]),
     "ssi_attn_varlen_bwd_rope": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int, c_int, c_int,
                                          c_int, _P]),
+    "ssi_attn_bwd_workspace_bytes": (c_int64, [c_int64, c_int64, c_int, c_int, c_int, c_int]),
+    "ssi_attn_varlen_bwd_ws": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int, c_int, c_int,
+                                       c_int, _P, c_int64, _P]),
     "ssi_doc_ranges": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P]),
     "ssi_swiglu_fwd": (c_int, [_P, _P, c_int64, c_int64, c_int, _P]),
     "ssi_swiglu_bwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P]),

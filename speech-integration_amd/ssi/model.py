@@ -529,6 +529,9 @@ class HipLlamaDecoder(nn.Module):
             else:
                 self._gemm(GEMM_NN, dy, self._view(name), dx)
 
+        # small micro-batches: dK / dV per query head + a reduction, in a workspace of the arena (0 bytes = the launch fills the chip as it is)
+        ws_bytes = ops.attn_bwd_workspace_bytes(B, S, H, KV, hd, dt) if T > 0 else 0
+        attn_ws = A.get("ws.attn", (ws_bytes,), torch.uint8) if ws_bytes else None
         dh = A.get("dh.a", (T, D), dt)
         ops.rmsnorm_bwd(d_hn, A.get(f"h{L}", (T, D), dt), self.norm.scale, A.get("rstdf", (T,), torch.float32), None, dh,
                         gv("norm"), ws, accumulate=acc)
@@ -560,7 +563,7 @@ class HipLlamaDecoder(nn.Module):
             delta = A.get("delta", (B * H * S,), torch.float32)
             # attention backward with the backward of the RoPE rotation fused into its epilogues: dqkv arrives in pre-RoPE space
             ops.attn_bwd(qkv, att, datt, A.get(f"lse.{l}", (B * H * S,), torch.float32), dqkv, delta, B, S, H, KV, hd, ds, de,
-                         rope_table=self._rope, positions=pos)
+                         rope_table=self._rope, positions=pos, workspace=attn_ws)
             dgrad(dqkv, f"L{l}.wqkv", dxn)
             if not defer:
                 wgrad(dqkv, xn1, f"L{l}.wqkv")

@@ -10,7 +10,7 @@ from torch import Tensor
 from . import _lib
 from ._lib import GEMM_NN, GEMM_NT, GEMM_TN, check, dtype_code, ptr, stream_ptr
 
-__all__ = ["lmhead_ce_fwd", "lmhead_ce_bwd", "doc_ranges", "embed_fwd", "embed_bwd", "rmsnorm_fwd", "rmsnorm_bwd", "rope_", "attn_fwd", "attn_bwd", "swiglu_fwd",
+__all__ = ["lmhead_ce_fwd", "lmhead_ce_bwd", "doc_ranges", "embed_fwd", "embed_bwd", "rmsnorm_fwd", "rmsnorm_bwd", "rope_", "attn_fwd", "attn_bwd", "attn_bwd_workspace_bytes", "swiglu_fwd",
            "swiglu_bwd", "gemm", "gemm_splitk", "splitk_choice", "gemm_swiglu_fwd", "gemm_swiglu_bwd", "transpose", "ce_fwd", "ce_reduce", "count_tokens", "scale_", "sumsq", "adamw_step", "set_impl",
            "GEMM_NT", "GEMM_NN", "GEMM_TN"]
 
@@ -132,14 +132,27 @@ def attn_fwd(qkv: Tensor, out: Tensor, lse: Tensor, batch: int, seq: int, n_head
                                           dtype_code(qkv.dtype), stream_ptr()), "ssi_attn_varlen_fwd")
 
 
+def attn_bwd_workspace_bytes(batch: int, seq: int, n_heads: int, n_kv: int, head_dim: int, dtype: torch.dtype) -> int:
+    """Bytes of workspace ``attn_bwd`` can use for this shape (0: none): small launches then run dK / dV per query head + a reduction."""
+    return int(_lib.load().ssi_attn_bwd_workspace_bytes(batch, seq, n_heads, n_kv, head_dim, dtype_code(dtype)))
+
+
 def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, dqkv: Tensor, delta: Tensor, batch: int, seq: int,
              n_heads: int, n_kv: int, head_dim: int, doc_start: Optional[Tensor] = None, doc_end: Optional[Tensor] = None,
-             rope_table: Optional[Tensor] = None, positions: Optional[Tensor] = None) -> None:
+             rope_table: Optional[Tensor] = None, positions: Optional[Tensor] = None, workspace: Optional[Tensor] = None) -> None:
     """dqkv of causal (or block-causal) GQA attention.  With ``rope_table`` the q / k parts come back in pre-RoPE space (the
-    backward of ``rope_`` fused in), positions as in ``rope_``."""
+    backward of ``rope_`` fused in), positions as in ``rope_``.  ``workspace`` (bytes, see ``attn_bwd_workspace_bytes``): optional."""
     assert qkv.stride(1) == 1 and dqkv.stride() == qkv.stride() and out.is_contiguous() and dout.is_contiguous()
     assert delta.dtype == torch.float32 and delta.numel() >= batch * n_heads * seq
     ds, de = _doc_ptrs(doc_start, doc_end, batch * seq)
+    if workspace is not None:
+        assert workspace.is_contiguous() and rope_table is None or (rope_table.dtype == torch.float32 and rope_table.is_contiguous())
+        assert positions is None or (positions.dtype == torch.int32 and positions.numel() == batch * seq)
+        check(_lib.load().ssi_attn_varlen_bwd_ws(ptr(qkv), qkv.stride(0), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), ds, de,
+                                                 ptr(rope_table), rope_table.shape[0] if rope_table is not None else 0, ptr(positions), batch,
+                                                 seq, n_heads, n_kv, head_dim, dtype_code(qkv.dtype), ptr(workspace),
+                                                 workspace.numel() * workspace.element_size(), stream_ptr()), "ssi_attn_varlen_bwd_ws")
+        return
     if rope_table is None:
         check(_lib.load().ssi_attn_varlen_bwd(ptr(qkv), qkv.stride(0), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), ds, de, batch,
                                               seq, n_heads, n_kv, head_dim, dtype_code(qkv.dtype), stream_ptr()), "ssi_attn_varlen_bwd")

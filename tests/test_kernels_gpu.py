@@ -569,6 +569,48 @@ def test_attention_dkv_pipelined_kernel_matches_the_128_key_kernel(ops, B, S, H,
     assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max()), "more than a bf16 step apart"
 
 
+@pytest.mark.parametrize("B,S,H,KV,rows", [(2, 256, 4, 1, None), (1, 512, 8, 2, None), (2, 2048, 32, 8, None),
+                                          (1, 1024, 8, 2, [[300, 37, 500, 187]])])
+@pytest.mark.parametrize("fused_rope", [False, True])
+def test_attention_backward_with_workspace_splits_dkv_over_the_query_heads(ops, B, S, H, KV, rows, fused_rope):
+    """ABI v6: with a caller-owned workspace, launches too small to fill the chip (the reference's default micro-batch of 2 x 2048 rows is
+    one: third case) run dK / dV as one workgroup per query head + a reduction over the heads.  Against the same call without workspace:
+    dQ untouched, dK / dV equal to the rounding of another summation order, reproducible; shapes that fill the chip ask for no workspace."""
+    from ssi import _lib
+    hd = 64
+    assert ops.attn_bwd_workspace_bytes(8, 2048, 32, 8, hd, torch.bfloat16) == 0          # the headline shape needs none
+    assert ops.attn_bwd_workspace_bytes(2, 2048, 32, 1, hd, torch.float32) == 0           # fp32: generic kernels
+    want = ops.attn_bwd_workspace_bytes(B, S, H, KV, hd, torch.bfloat16)
+    assert want == (H // KV) * B * S * KV * 128 * 4
+    qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=71)
+    do = rnd(B * S, H * hd, dtype=torch.bfloat16, seed=72)
+    ds = de = None
+    if rows is not None:
+        ds, de = (t.to(DEV) for t in _doc_arrays(rows, S))
+    table = rnd(S + 8, hd // 2, 2, dtype=torch.float32, seed=73).to(DEV) if fused_rope else None
+    prev = ops.set_impl(_lib.IMPL_MFMA)
+    try:
+        x, dout = qkv.to(DEV), do.to(DEV)
+        out = torch.empty(B * S, H * hd, dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+        delta = torch.empty_like(lse)
+        ops.attn_fwd(x, out, lse, B, S, H, KV, hd, ds, de)
+        res = []
+        for ws in (None, torch.empty(want, dtype=torch.uint8, device=DEV), torch.full((want + 64,), 255, dtype=torch.uint8, device=DEV)):
+            d = torch.full_like(x, float("nan"))
+            ops.attn_bwd(x, out, dout, lse, d, delta, B, S, H, KV, hd, ds, de, rope_table=table, workspace=ws)
+            res.append(d.cpu().float())
+    finally:
+        ops.set_impl(prev)
+    plain, split, split2 = res
+    assert torch.isfinite(split).all() and torch.equal(split, split2), "not reproducible / workspace contents leak into the result"
+    assert torch.equal(plain[:, : H * hd], split[:, : H * hd])
+    a, b = plain[:, H * hd:], split[:, H * hd:]
+    assert not torch.equal(a, b), "the head-split form did not run"
+    assert float((a - b).norm() / a.norm()) <= 3e-4
+    assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max())
+
+
 def _doc_arrays(seq_lens_rows, S):
     """doc_start / doc_end (int32 [B*S]) from per-row lists of document lengths (each row sums to S)."""
     ds, de = [], []

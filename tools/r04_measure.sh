@@ -15,7 +15,9 @@ run padded --padded
 run padded_as_is --padded --no-unpad
 run b2_s2048 --batch 2 --seq 2048
 run b16_s768 --batch 16 --seq 768
-for f in dsus8192 s4096 packed padded padded_as_is b2_s2048 b16_s768; do python - <<PY
+run sft_default_b2_s2048_ga4 --batch 2 --seq 2048 --grad-accum 4 --steps 10
+run cpt_default_b16_s768_ga4 --batch 16 --seq 768 --grad-accum 4 --steps 6 --warmup 2
+for f in dsus8192 s4096 packed padded padded_as_is b2_s2048 b16_s768 sft_default_b2_s2048_ga4 cpt_default_b16_s768_ga4; do python - <<PY
 import json
 d=json.load(open("gpurun_out/${tag}_${f}_bench.json"))
 print("${f}", round(d["value"]), "tokens/s", round(d["ms_per_step"],2), "ms", d.get("mfma_roofline_frac_step"))
