@@ -598,8 +598,8 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_bwd_dq_kernel
 // buffered, one step ahead), so Q and dO cross the L2 -> CU path once per 128 keys instead of once per 32, and the sum
 // over the query heads of the group happens in registers: no cross-wave reduction, no partial buffers, one writer per
 // output element.
-// HSPLIT (round 4): one workgroup per QUERY HEAD of the group instead of one for all `rep` of them; its dK / dV sums leave as fp32 partial
-// rows in `partial` ([head of the group][B * S][KV][dK 64 | dV 64]) and attn_dkv_head_reduce_kernel adds the heads in a fixed order.  For
+// HSPLIT (round 4): a workgroup sweeps `heads_per_wg` of the group's query heads instead of all `rep` of them; its dK / dV sums leave as fp32
+// partial rows in `partial` ([slot = head / heads_per_wg][B * S][KV][dK 64 | dV 64]) and attn_dkv_head_reduce_kernel adds the slots in a fixed order.  For
 // launches whose workgroups cannot fill the chip: the longest workgroup IS the launch (B = 2, S = 2048: 256 workgroups, the heaviest with
 // 256 steps: 176 us per layer where 65 is the launch's share of the chip), and a workgroup's steps are queries x heads.
 template <bool HSPLIT>
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
                                                            const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
                                                            const int32_t* __restrict__ doc_end, const float* __restrict__ rope,
                                                            const int32_t* __restrict__ positions, int S, int H, int KV,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial, int heads_per_wg) {
     // ring of RING step buffers: [Q tile 4 KiB | dO tile 4 KiB | lse 128 B | delta 128 B]; requests run RING-1 steps ahead
     constexpr int SB = 8192 + 256;
     constexpr int RING = DKV_RING;
@@ -616,14 +616,16 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
     TRACE_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep_all = H / KV;
-    const int rep = HSPLIT ? 1 : rep_all;  // query heads this workgroup sweeps
+    const int rep = HSPLIT ? heads_per_wg : rep_all;  // query heads this workgroup sweeps
+    const int n_slots = rep_all / rep;                 // workgroups (and partial rows) per key group
     const int ngrp = S / 128;
-    int kgrp, pair_, head0 = 0;  // low key groups (most work) are dispatched first
+    int kgrp, pair_, head0 = 0, slot = 0;  // low key groups (most work) are dispatched first
     if (HSPLIT) {
         int r;
-        block_to_work(ngrp * rep_all, (int)(gridDim.x / (ngrp * rep_all)), r, pair_);
-        kgrp = r / rep_all;
-        head0 = r % rep_all;
+        block_to_work(ngrp * n_slots, (int)(gridDim.x / (ngrp * n_slots)), r, pair_);
+        kgrp = r / n_slots;
+        slot = r % n_slots;
+        head0 = slot * rep;
     } else {
         block_to_work(ngrp, (int)(gridDim.x / ngrp), kgrp, pair_);
     }
@@ -826,8 +828,8 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
     }
 #endif
     if constexpr (HSPLIT) {  // raw fp32 sums of this head: [head][row][kv head][dK 64 | dV 64]; scale, RoPE backward and rounding happen after the heads are added
-        const int64_t t_rows = (int64_t)(gridDim.x / (ngrp * rep_all)) / KV * S;  // B * S
-        float* prow = partial + (((int64_t)head0 * t_rows + row0 + kg) * KV + kvh) * 128;
+        const int64_t t_rows = (int64_t)(gridDim.x / (ngrp * n_slots)) / KV * S;  // B * S
+        float* prow = partial + (((int64_t)slot * t_rows + row0 + kg) * KV + kvh) * 128;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -1314,10 +1316,20 @@ __global__ __launch_bounds__(256) void attn_dkv_head_reduce_kernel(const float* 
 }
 
 // fp32 workspace the head-split dK / dV form wants for this shape (0: the launch fills the chip without it, or a single head per kv head)
-int64_t ssi_attn_mfma_bwd_workspace_bytes(int64_t batch, int64_t seq, int n_heads, int n_kv) {
+// Workgroups per key group of the split form: all `rep` heads apart below 512 workgroups (two fit a CU: 512 fill the chip once, and the heaviest
+// of them — queries x heads steps — is as long as the launch), two halves below 1024 (one long packed row: B = 1, S = 11 520 gives 720 workgroups
+// whose heaviest sweeps a whole document x 4 heads = 256 steps where the chip's share per slot is 127); 1 = unsplit.
+static int dkv_head_slots(int64_t batch, int64_t seq, int n_heads, int n_kv) {
     const int rep = n_heads / n_kv;
-    if (rep <= 1 || seq % 128 || batch * n_kv * (seq / 128) >= 2 * 256) return 0;  // two workgroups per CU: 512 of them fill the chip
-    return (int64_t)rep * batch * seq * n_kv * 128 * (int64_t)sizeof(float);
+    const int64_t wgs = batch * n_kv * (seq / 128);
+    if (rep <= 1 || seq % 128) return 1;
+    if (wgs < 512) return rep;
+    if (wgs < 1024 && rep % 2 == 0) return 2;
+    return 1;
+}
+int64_t ssi_attn_mfma_bwd_workspace_bytes(int64_t batch, int64_t seq, int n_heads, int n_kv) {
+    const int slots = dkv_head_slots(batch, seq, n_heads, n_kv);
+    return slots <= 1 ? 0 : (int64_t)slots * batch * seq * n_kv * 128 * (int64_t)sizeof(float);
 }
 
 bool ssi_attn_mfma_supported(int64_t ld, int64_t batch, int64_t seq, int n_heads, int n_kv, int head_dim, int dtype) {
@@ -1368,14 +1380,16 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
         // small launches: one workgroup per query head + a reduction, when the caller brought the workspace (SSI_ATTN_DKV=3: never)
         const int64_t want = ssi_attn_mfma_bwd_workspace_bytes(batch, seq, n_heads, n_kv);
         if (want > 0 && workspace && workspace_bytes >= want && ((uintptr_t)workspace & 15) == 0 && !(sel && sel[0] == '3')) {
-            hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3((unsigned)(batch * n_kv * (seq / 128) * rep)), dim3(256), 0, st, (const bf16_t*)qkv, ld,
-                               (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, rope, positions, (int)seq, n_heads, n_kv, (float*)workspace);
+            const int slots = dkv_head_slots(batch, seq, n_heads, n_kv);
+            hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3((unsigned)(batch * n_kv * (seq / 128) * slots)), dim3(256), 0, st, (const bf16_t*)qkv, ld,
+                               (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, rope, positions, (int)seq, n_heads, n_kv, (float*)workspace,
+                               rep / slots);
             SSI_LAUNCH_CHECK();
             hipLaunchKernelGGL(attn_dkv_head_reduce_kernel, dim3((unsigned)ssi_cdiv(batch * seq * n_kv * 32, 256)), dim3(256), 0, st,
-                               (const float*)workspace, rep, batch * seq, n_kv, (bf16_t*)dqkv, ld, n_heads, rope, positions, (int)seq);
+                               (const float*)workspace, slots, batch * seq, n_kv, (bf16_t*)dqkv, ld, n_heads, rope, positions, (int)seq);
         } else {
             hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3((unsigned)(batch * n_kv * (seq / 128))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
-                               (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, rope, positions, (int)seq, n_heads, n_kv, (float*)nullptr);
+                               (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, rope, positions, (int)seq, n_heads, n_kv, (float*)nullptr, rep);
         }
     }
     SSI_LAUNCH_CHECK();

@@ -570,7 +570,8 @@ def test_attention_dkv_pipelined_kernel_matches_the_128_key_kernel(ops, B, S, H,
 
 
 @pytest.mark.parametrize("B,S,H,KV,rows", [(2, 256, 4, 1, None), (1, 512, 8, 2, None), (2, 2048, 32, 8, None),
-                                          (1, 1024, 8, 2, [[300, 37, 500, 187]])])
+                                          (1, 1024, 8, 2, [[300, 37, 500, 187]]),
+                                          (1, 11520, 32, 8, [[1807, 2038, 1909, 1924, 1500, 2048, 294]])])   # one long packed row: 720 workgroups, two heads each
 @pytest.mark.parametrize("fused_rope", [False, True])
 def test_attention_backward_with_workspace_splits_dkv_over_the_query_heads(ops, B, S, H, KV, rows, fused_rope):
     """ABI v6: with a caller-owned workspace, launches too small to fill the chip (the reference's default micro-batch of 2 x 2048 rows is
@@ -581,7 +582,8 @@ def test_attention_backward_with_workspace_splits_dkv_over_the_query_heads(ops, 
     assert ops.attn_bwd_workspace_bytes(8, 2048, 32, 8, hd, torch.bfloat16) == 0          # the headline shape needs none
     assert ops.attn_bwd_workspace_bytes(2, 2048, 32, 1, hd, torch.float32) == 0           # fp32: generic kernels
     want = ops.attn_bwd_workspace_bytes(B, S, H, KV, hd, torch.bfloat16)
-    assert want == (H // KV) * B * S * KV * 128 * 4
+    slots = (H // KV) if B * KV * (S // 128) < 512 else 2   # all heads apart below 512 workgroups, two halves below 1024
+    assert want == slots * B * S * KV * 128 * 4
     qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=71)
     do = rnd(B * S, H * hd, dtype=torch.bfloat16, seed=72)
     ds = de = None
