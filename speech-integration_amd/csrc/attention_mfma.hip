@@ -501,6 +501,7 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_bwd_dq_kernel
             __builtin_amdgcn_sched_barrier(0);
 #ifdef DQ_STAMP
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
             QSTAMP(1)  // 16 row-fragment reads landed
             f32x16 sacc[2], pacc[2];
 #pragma unroll
@@ -547,7 +548,6 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_bwd_dq_kernel
                 for (int db = 0; db < 2; ++db)
                     dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[s][db], dsf, dq[db], 0, 0, 0);
             }
-#endif
             QSTAMP(5)  // conversions + 8 dQ MFMAs issued
         }
     };
