@@ -32,8 +32,7 @@ namespace {
 // Backward of the interleaved RoPE on the 4 consecutive head dimensions d0 .. d0+3 of one row (two adjacent pairs), applied to
 // the gradient AFTER its rounding to bf16 and rounded again, i.e. exactly what ssi_rope_inplace(inverse) does to the stored
 // tensor (torchtune applies RoPE as a separate bf16 -> fp32 -> bf16 op).  tb = table row of the position: [hd/2][cos, sin].
-__device__ __forceinline__ bf16x4 unrope4(bf16x4 v, const float* __restrict__ tb, int d0) {
-    const f32x4 cs = *reinterpret_cast<const f32x4*>(tb + d0);  // (cos, sin) of pairs d0/2 and d0/2 + 1
+__device__ __forceinline__ bf16x4 unrope4(bf16x4 v, f32x4 cs) {  // cs = (cos, sin) of pairs d0/2 and d0/2 + 1
     const float x0 = (float)v[0], x1 = (float)v[1], x2 = (float)v[2], x3 = (float)v[3];
     bf16x4 o;
     o[0] = (bf16_t)(x0 * cs[0] + x1 * cs[1]);
@@ -41,6 +40,9 @@ __device__ __forceinline__ bf16x4 unrope4(bf16x4 v, const float* __restrict__ tb
     o[2] = (bf16_t)(x2 * cs[2] + x3 * cs[3]);
     o[3] = (bf16_t)(x3 * cs[2] - x2 * cs[3]);
     return o;
+}
+__device__ __forceinline__ bf16x4 unrope4(bf16x4 v, const float* __restrict__ tb, int d0) {
+    return unrope4(v, *reinterpret_cast<const f32x4*>(tb + d0));
 }
 
 // Workgroup -> (rank of the block inside its (batch, kv head) pair, pair).  Workgroups go to the 8 XCDs round-robin by
@@ -233,6 +235,29 @@ template <int SWZ_K, int SWZ_V> struct KvTileDma {
             dma16(lds_piece + slot_bytes + 8192 + p * ANW * 1024, vv[p], rs, soff);
         }
     }
+    // request i (0 .. 2 ANP - 1) of a tile alone: K piece i >> 1 (even i) or V piece i >> 1 (odd i)
+    __device__ __forceinline__ void piece(int t, unsigned slot_bytes, int i) const {
+        const unsigned soff = (unsigned)t * tile_bytes;
+        const int p = i >> 1;
+        if (i & 1) dma16(lds_piece + slot_bytes + 8192 + p * ANW * 1024, vv[p], rs, soff);
+        else dma16(lds_piece + slot_bytes + p * ANW * 1024, vk[p], rs, soff);
+    }
+};
+
+// A [64 rows][64] bf16 tile (64 consecutive rows of one head's column block) into LDS by ONE wave, SWZ_ROW image: 8 requests of 8 rows x
+// 128 B — whole 128-B lines, where a fragment load straight from global memory (lane = row) touches 32 rows x 32 B per instruction.
+struct RowTileDma {
+    u32x4 rs;
+    unsigned voff[2];  // per-lane source byte offset inside a request, for even / odd requests (the swizzle's bit 2 follows the request)
+    unsigned step;     // source bytes from one request to the next
+    __device__ __forceinline__ void init(const bf16_t* base, int64_t ld, int lane) {
+        rs = buffer_rsrc(base);
+#pragma unroll
+        for (int par = 0; par < 2; ++par)  // swz<SWZ_ROW>(8 i + (l >> 3)) = (l >> 4) ^ 4 (i & 1)
+            voff[par] = (unsigned)(((lane >> 3) * ld + ((lane & 7) ^ (lane >> 4) ^ (4 * par)) * 8) * 2);
+        step = (unsigned)(8 * ld * 2);
+    }
+    __device__ __forceinline__ void request(int i, unsigned lds_tile) const { dma16(lds_tile + i * 1024, voff[i & 1], rs, (unsigned)i * step); }
 };
 
 // =====================================================================================================================
@@ -590,6 +615,458 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_bwd_dq_kernel
 }
 
 // =====================================================================================================================
+// backward: dQ — round 4: one wave per SIMD, hand-placed software pipeline, persistent workgroups
+// (plain causal rows, 4 query heads per kv head, S a multiple of 512)
+// =====================================================================================================================
+// The recipe of attn_bwd_dkv2_kernel (further down: read its header first) applied to dQ.  An ITEM = 64 queries x the 4 query heads of a kv
+// head (wave w = head w), sweeping the 64-key tiles 0 .. its own; a UNIT = (32-key block kb, 32-query block qb) of a tile: 8 S^T / dP^T
+// MFMAs (SP), 16 x { fma, exponential, multiply } + 8 packed conversions (SM), 4 dQ^T MFMAs (DQ).  A PERIOD = 12 MFMAs: DQ of unit u-1
+// (MFMAs 0-3), SP of unit u+1 (4-11, S first), SM of unit u spread over the 12 gaps; four periods = one tile = one trip of the loop (one basic
+// block, one barrier, four LDS-DMA requests per wave, 32 LDS reads: 8 per period, each >= 8 gaps ahead of its first use).  K / V row fragments
+// and K transposed fragments of a key block serve both query blocks.  Q / dO operand fragments and the dQ sums live in accumulation
+// registers; delta rides in as the C operand of the dP chain (a replicated register set that is never dead), lse as the addend of the
+// exponent's fma (which also carries the 1/sqrt(d): the Q fragments stay as loaded).  Only the last tile of an item (its diagonal) needs the
+// causal mask: a second, masked loop of one trip behind the first.
+//
+// With 400 registers per wave a CU holds ONE workgroup, so whatever an item does before and behind its tiles — waiting for its operands,
+// converting them, storing dQ — is time the matrix pipe stands still: ~19 000 cycles per item against ~2 350 per tile and 16.5 tiles per item
+// when every item was a workgroup (profiles/r04_dq2_stamps.txt).  Hence the workgroups are PERSISTENT: a workgroup walks DQ2_ITEMS = 8 query
+// blocks of one (batch, kv head) — blocks g, 2W-1-g, 2W+g, 4W-1-g, ... of the S/64, W = S/512 workgroups per pair, every workgroup the same
+// number of tiles — and the Q, dO and O rows of the NEXT item are requested (LDS-DMA, whole 128-B lines, into per-wave images: no barrier)
+// while the current item computes; its lse one item ahead into registers; the RoPE table rows for the store into LDS as well.
+constexpr int DQ2_RING = 3, DQ2_ITEMS = 8;
+constexpr int DQ2_STAGE = DQ2_RING * 16384;            // per wave: [Q | dO | O][64][64] bf16 images of the item's rows of its head
+constexpr int DQ2_ROPE = DQ2_STAGE + 4 * 3 * 8192;     // [64 queries][64] fp32 table rows, 16-B chunks XOR (row & 15)
+constexpr int DQ2_LDS = DQ2_ROPE + 64 * 256;           // 160 KiB: all of a CU's LDS
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    bf16x2_ v;
+    v[0] = (bf16_t)a;
+    v[1] = (bf16_t)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// The vector instructions of a dQ unit beside its 12 MFMAs: per pair j of accumulator elements two fmas (kind 0: 2 issue slots), two
+// exponentials (kinds 1, 2: 2 slots each), two multiplies (kind 3) and a packed conversion (kind 4: 1 slot): 72 slots, dealt to the 12 gaps
+// by their running slot count in an order that never lets an instruction read its predecessor's result: fma j+1, exp j, exp j, multiply
+// j-1, conversion j-2.  (Packed fp32 — v_pk_fma_f32, v_pk_mul_f32 — would halve the fma / multiply slots, but beside a running MFMA one
+// packed instruction costs ~14 cycles against ~4.5 for a scalar one: tools/micro/mfma_gap.hip, 63 cycles per gap for 4 of them.)
+struct Dq2Plan {
+    int n, kind[40], pair[40], gap[40];
+};
+constexpr Dq2Plan dq2_make_plan() {
+    Dq2Plan p{};
+    int n = 0;
+    auto push = [&](int kind, int j) {
+        if (j < 0 || j > 7) return;
+        p.kind[n] = kind;
+        p.pair[n] = j;
+        ++n;
+    };
+    push(0, 0);
+    for (int j = 0; j < 10; ++j) {
+        push(0, j + 1);
+        push(1, j);
+        push(2, j);
+        push(3, j - 1);
+        push(4, j - 2);
+    }
+    p.n = n;
+    int slots = 0;
+    for (int i = 0; i < n; ++i) {
+        const int g = slots * 12 / 72;
+        p.gap[i] = g > 11 ? 11 : g;
+        slots += p.kind[i] == 4 ? 1 : 2;
+    }
+    return p;
+}
+constexpr Dq2Plan DQ2_PLAN = dq2_make_plan();
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ out,
+                                                              const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                              float* __restrict__ delta, bf16_t* __restrict__ dqkv,
+                                                              const float* __restrict__ rope, int S, int H, int KV, int W) {
+    __shared__ __attribute__((aligned(16))) char smem[DQ2_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    // workgroup -> ((batch, kv head) pair, group g of its query blocks); an XCD gets whole pairs (their K / V stay in one L2)
+    int pair, g;
+    {
+        const int n_pairs = (int)gridDim.x / W, id = (int)blockIdx.x;
+        if (n_pairs % 8 == 0) {
+            const int ppx = n_pairs / 8, k = id >> 3;
+            pair = (id & 7) * ppx + k / W;
+            g = k % W;
+        } else {
+            pair = id / W;
+            g = id % W;
+        }
+    }
+    const int kvh = pair % KV, b = pair / KV;
+    const int head = kvh * 4 + wave;
+    const int64_t row0 = (int64_t)b * S, ldo = (int64_t)H * HD;
+    const bf16_t* kbase = qkv + row0 * ld + (int64_t)H * HD + (int64_t)kvh * HD;
+    // item i (heaviest first) -> query block: the pairs (2W-1-g, g) of the four 2W-blocks, from the top
+    auto item_block = [&](int i) __attribute__((always_inline)) {
+        const int u = (DQ2_ITEMS / 2 - 1) - (i >> 1);
+        return u * 2 * W + ((i & 1) ? g : 2 * W - 1 - g);
+    };
+
+    KvTileDma<SWZ_DUAL, SWZ_ROW> kvdma;
+    kvdma.init(kbase, ld, KV * HD, smem, wave, lane);
+    // requests of a [64][64] image by one wave (see RowTileDma): per-lane source offsets for rows of stride ld (Q) and ldo (dO, O)
+    unsigned vq[2], vo[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int chunk = (lane & 7) ^ (lane >> 4) ^ (4 * par);
+        vq[par] = (unsigned)(((lane >> 3) * ld + chunk * 8) * 2);
+        vo[par] = (unsigned)(((lane >> 3) * ldo + chunk * 8) * 2);
+    }
+    const char* stage = smem + DQ2_STAGE + wave * (3 * 8192);
+    const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)stage);
+    // Q, dO and O rows of item block jq of this wave's head: 24 requests
+    auto request_stage = [&](int jq) __attribute__((always_inline)) {
+        const int64_t r = row0 + jq * 64;
+        const u32x4 rq = buffer_rsrc(qkv + r * ld + (int64_t)head * HD), rd = buffer_rsrc(dout + r * ldo + (int64_t)head * HD),
+                    ro = buffer_rsrc(out + r * ldo + (int64_t)head * HD);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            dma16(stage_lds + i * 1024, vq[i & 1], rq, (unsigned)(i * 8 * ld * 2));
+            dma16(stage_lds + 8192 + i * 1024, vo[i & 1], rd, (unsigned)(i * 8 * ldo * 2));
+            dma16(stage_lds + 16384 + i * 1024, vo[i & 1], ro, (unsigned)(i * 8 * ldo * 2));
+        }
+    };
+    // RoPE table rows q0 .. q0 + 63 (256 B each) of an item: 16 pieces of 4 rows, wave w the pieces w, w + 4, w + 8, w + 12; the 16-B chunk c
+    // of row r lies at chunk c ^ (r & 15).  Without a table the requests read the head of qkv instead (and the store ignores them).
+    const unsigned rope_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)(smem + DQ2_ROPE));
+    const unsigned vrope = (unsigned)((lane >> 4) * 256 + (((lane & 15) ^ ((4 * wave + (lane >> 4)) & 15)) * 16));
+    const u32x4 rope_rs = buffer_rsrc(rope ? (const void*)rope : (const void*)qkv);
+    auto lse_of = [&](int jq, int qb) __attribute__((always_inline)) { return lse[((int64_t)b * H + head) * S + jq * 64 + 32 * qb + (lane & 31)]; };
+
+    // ---- per-tile register state ------------------------------------------------------------------------------------------------------------
+    bf16x8 qf[2][4], dof[2][4];    // B operands: lane = query q0 + 32 qb + (l & 31), d = 16 ks + 8 h + j
+    f32x16 pdl[2];                 // -delta of the lane's query in all 16 registers: C operand of the dP^T chain
+    float nlq[2];                  // -lse * log2(e): p = exp2(S^T * log2(e) / 8 + nlq)
+    int qg[2];
+    f32x16 dq[2][2];
+    f32x16 sacc[2], pacc[2];       // [unit parity]: S^T and dP'^T of the unit in flight
+    bf16x8 rowK[2][4], rowV[2][4]; // [kb]: K / V row fragments (A operands of the S^T / dP^T products)
+    s16x4 ktrh[4][2][2];           // [k-step s][db][half]: K transposed fragments (A operands of the dQ^T products); s = 2 kb, 2 kb + 1
+    u32x4 dsu[2][2];               // [unit parity][s2]: dS^T of a unit as bf16 operand fragments
+    unsigned ring_cur, ring_nxt, ring_n2;  // byte offsets of the slots of tiles t, t+1, t+2
+    constexpr float SCALE2 = LOG2E * 0.125f;  // log2(e) / sqrt(d)
+
+    auto tr_frag = [&](const s16x4 (&hv)[2]) __attribute__((always_inline)) {
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(hv[0], hv[1], 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // read i (0..7) of the row fragments of key block kb of the tile at `slot`: 0-3 K, 4-7 V
+    auto read_rows = [&](unsigned slot, int kb, int i) __attribute__((always_inline)) {
+        const char* kt = smem + slot;
+        if (i < 4) rowK[kb][i] = frag_row<SWZ_DUAL>(kt, kb * 32, i, lane);
+        else rowV[kb][i - 4] = frag_row<SWZ_ROW>(kt + 8192, kb * 32, i - 4, lane);
+    };
+    // read i (0..7) of the transposed fragments of key block kb: k-step 2 kb + (i >> 2), db (i >> 1) & 1, half i & 1 — the order of their use
+    auto read_tr = [&](unsigned slot, int kb, int i) __attribute__((always_inline)) {
+        const int sI = 2 * kb + (i >> 2), db = (i >> 1) & 1;
+        ktrh[sI][db][i & 1] = frag_tr_half<SWZ_DUAL>(smem + slot, sI * 16, db * 32, lane, i & 1);
+    };
+    // S^T / dP^T product m (0..7) of unit (kb, qb) into register set `par`: the S chain first (see sp_mfma of attn_bwd_dkv2_kernel)
+    auto sp_mfma = [&](int par, int kb, int qb, int m) __attribute__((always_inline)) {
+        const int ks = m & 3;
+        if (m == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(sacc[par]) : "v"(rowK[kb][0]), "a"(qf[qb][0]));
+        else if (m == 4) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(pacc[par]) : "v"(rowV[kb][0]), "a"(dof[qb][0]), "v"(pdl[qb]));
+        else if (m > 4) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(pacc[par]) : "v"(rowV[kb][ks]), "a"(dof[qb][ks]));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[par]) : "v"(rowK[kb][ks]), "a"(qf[qb][ks]));
+    };
+    // dQ^T product i (0..3) of unit (kb, qb) whose dS^T sits in dsu[par]: k-step s2 = i >> 1 of the key block, d block i & 1
+    auto dq_mfma = [&](int par, int kb, int qb, int i) __attribute__((always_inline)) {
+        const int s2 = i >> 1, db = i & 1;
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dq[qb][db]) : "v"(tr_frag(ktrh[2 * kb + s2][db])), "v"(dsu[par][s2]));
+    };
+    // exponentials of unit (kb, qb) in register set `par`, gap g of 12: the instructions DQ2_PLAN puts there
+    f32x2 ev[8], dsv[8];
+    float pv[16];
+    // the causal mask inside a DIAGONAL 32 x 32 block (kb == qb of the diagonal tile): key row rowmap(r, h) against query column l & 31 —
+    // the same 16 lane masks for every item.  Of the other two blocks of that tile, (kb 0, qb 1) is all visible and (kb 1, qb 0) all masked.
+    bool beyond[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) beyond[r] = rowmap(r, h) > (lane & 31);
+    auto sm_gap = [&](auto edge_c, int par, int kb, int qb, int k0, int gap) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_c)::value;
+        if (EDGE && kb == 1 && qb == 0) {  // nothing visible: dS^T = 0
+            if (gap == 0) dsu[par][0] = dsu[par][1] = u32x4{0u, 0u, 0u, 0u};
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < DQ2_PLAN.n; ++i) {
+            if (DQ2_PLAN.gap[i] != gap) continue;
+            const int j = DQ2_PLAN.pair[i], kind = DQ2_PLAN.kind[i];
+            if (kind == 0) {
+                ev[j][0] = fmaf(sacc[par][2 * j], SCALE2, nlq[qb]);
+                ev[j][1] = fmaf(sacc[par][2 * j + 1], SCALE2, nlq[qb]);
+            } else if (kind == 1 || kind == 2) {
+                const int r = 2 * j + kind - 1;
+                float p = __builtin_amdgcn_exp2f(ev[j][kind - 1]);
+                if (EDGE && kb == qb && beyond[r]) p = 0.f;  // keys beyond the query contribute nothing
+                pv[r] = p;
+            } else if (kind == 3) {
+                dsv[j][0] = pv[2 * j] * pacc[par][2 * j];  // dS^T (the 1/sqrt(d) factor is applied once at the end)
+                dsv[j][1] = pv[2 * j + 1] * pacc[par][2 * j + 1];
+            } else {
+                dsu[par][j >> 2][j & 3] = pack_bf16(dsv[j][0], dsv[j][1]);
+            }
+        }
+    };
+    // one period: SM of unit `cur`, DQ of the unit before it, SP of the unit behind it; 8 LDS reads; optionally the ring barrier in front and
+    // four LDS-DMA requests behind.  Units are (kb, qb, register set); k0 = first key of `cur`'s tile.
+    struct Unit { int kb, qb, par; };
+    auto period = [&](auto edge_c, auto sync_c, auto sp_c, Unit prev, Unit cur, Unit next, int k0, auto reads, auto tail, auto landed) __attribute__((always_inline)) {
+        if (decltype(sync_c)::value) {
+            // own requests of tile t+1 have landed (those of t+2 stay in flight) ... and everybody's; every wave is done with tile t
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            ring_barrier();
+        }
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+            if (m < 4) dq_mfma(prev.par, prev.kb, prev.qb, m);
+            else if (decltype(sp_c)::value) sp_mfma(next.par, next.kb, next.qb, m - 4);
+            __builtin_amdgcn_sched_barrier(0);  // the MFMA first: the first multiply of a period reads the dP^T chain finished one MFMA ago
+            sm_gap(edge_c, cur.par, cur.kb, cur.qb, k0, m);
+            reads(m);
+            tail(m);
+            if (m == 11) landed();  // the period's 8 LDS reads (issued in gaps 0-7): ONE wait here instead of hipcc's one per first use
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // "these registers have been read": hipcc puts its s_waitcnt lgkmcnt in front, and none at the uses behind
+    auto rows_landed = [&](int kb) __attribute__((always_inline)) {
+        asm volatile("" ::"v"(rowK[kb][0]), "v"(rowK[kb][1]), "v"(rowK[kb][2]), "v"(rowK[kb][3]), "v"(rowV[kb][0]), "v"(rowV[kb][1]), "v"(rowV[kb][2]),
+                     "v"(rowV[kb][3]));
+    };
+    auto tr_landed = [&](int kb) __attribute__((always_inline)) {
+        asm volatile("" ::"v"(ktrh[2 * kb][0][0]), "v"(ktrh[2 * kb][0][1]), "v"(ktrh[2 * kb][1][0]), "v"(ktrh[2 * kb][1][1]), "v"(ktrh[2 * kb + 1][0][0]),
+                     "v"(ktrh[2 * kb + 1][0][1]), "v"(ktrh[2 * kb + 1][1][0]), "v"(ktrh[2 * kb + 1][1][1]));
+    };
+    auto none = [&](int) __attribute__((always_inline)) {};
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    const Unit U0{0, 0, 0}, U1{0, 1, 1}, U2{1, 0, 0}, U3{1, 1, 1};
+    // hipcc does not know the asm statements above to be MFMAs.  Where it moves their registers itself — at the ends of the loops below — its
+    // copies get no wait states: a copy reading a result still in the pipe, or an MFMA reading an accumulator register written just before it
+    // (that one cost element 0 of a dQ block).  MFMA_DRAIN / MFMA_GUARD at every such place.
+#define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
+#define MFMA_GUARD() asm volatile("s_nop 7" ::: "memory")
+
+    // -DDQ2_STAMP (debug build, tools/attn_dq_check.py stamps): cycles of wave 0 per phase of an item, summed over the workgroup's items, left
+    // in the first floats of its LAST item's first dq row (the lightest block of the group) together with the 100 MHz clock's count
+#ifdef DQ2_STAMP
+    unsigned long long stq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stq_last = __builtin_readcyclecounter();
+    const unsigned long long stq_begin = stq_last, stq_rt0 = __builtin_amdgcn_s_memrealtime();
+#define STAMPQ(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); stq_acc[i] += now_ - stq_last; stq_last = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMPQ(i) {}
+#endif
+    // ---- before the first item: its rows, its lse -------------------------------------------------------------------------------------------
+    // the first three key tiles of an item of nt tiles; behind the last tile the last tile is requested again (into a slot nobody reads), so
+    // that the counted vmcnt waits hold without a tail case and a trip has no branch
+    auto request_first_tiles = [&](int nt) __attribute__((always_inline)) {
+        kvdma.tile(0, 0);
+        kvdma.tile(nt > 1 ? 1 : 0, 16384);
+        kvdma.tile(nt > 2 ? 2 : nt - 1, 32768);
+    };
+    float lqn[2];
+    {
+        const int j0 = item_block(0);
+        request_first_tiles(j0 + 1);
+        request_stage(j0);
+        lqn[0] = lse_of(j0, 0);
+        lqn[1] = lse_of(j0, 1);
+    }
+
+    for (int it = 0; it < DQ2_ITEMS; ++it) {
+        const int jq = item_block(it), jn = item_block(it + 1 < DQ2_ITEMS ? it + 1 : it);
+        const int q0 = jq * 64, nt = jq + 1;  // key tiles 0 .. jq; the last one holds the diagonal
+        const float lq0 = lqn[0], lq1 = lqn[1];
+        // everything this wave has asked for is there: the item's rows (asked for an item ago), its first three tiles (asked for in front of
+        // the store of the item before), that store
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(lq0), "v"(lq1) : "memory");
+        STAMPQ(0)
+        bf16x8 oraw[2][4];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                qf[qb][ks] = frag_row<SWZ_ROW>(stage, 32 * qb, ks, lane);
+                dof[qb][ks] = frag_row<SWZ_ROW>(stage + 8192, 32 * qb, ks, lane);
+                oraw[qb][ks] = frag_row<SWZ_ROW>(stage + 16384, 32 * qb, ks, lane);
+            }
+        // in registers: the images are free for the next item's rows (this wave's own images: no barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(oraw[1][3]), "v"(dof[1][3]), "v"(qf[1][3]) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        lqn[0] = lse_of(jn, 0);
+        lqn[1] = lse_of(jn, 1);
+        // 28 requests — the table rows of THIS item (nobody reads the old ones any more: barrier at the end of the item before) and the next
+        // item's rows — dealt over the 8 steps of the delta sums: back to back, four waves' requests queue up in front of the CU's one
+        // address unit (~150 cycles each where a request inside the tile loop costs 40)
+        const int64_t rn = row0 + jn * 64;
+        const u32x4 rq = buffer_rsrc(qkv + rn * ld + (int64_t)head * HD), rd = buffer_rsrc(dout + rn * ldo + (int64_t)head * HD),
+                    ro = buffer_rsrc(out + rn * ldo + (int64_t)head * HD);
+        auto request = [&](int i) __attribute__((always_inline)) {
+            if (i < 4) {
+                dma16(rope_lds + (wave + 4 * i) * 1024, vrope, rope_rs, (unsigned)((rope ? q0 * 256 : 0) + (wave + 4 * i) * 1024));
+            } else {
+                const int j = (i - 4) / 3, which = (i - 4) % 3;
+                if (which == 0) dma16(stage_lds + j * 1024, vq[j & 1], rq, (unsigned)(j * 8 * ld * 2));
+                else if (which == 1) dma16(stage_lds + 8192 + j * 1024, vo[j & 1], rd, (unsigned)(j * 8 * ldo * 2));
+                else dma16(stage_lds + 16384 + j * 1024, vo[j & 1], ro, (unsigned)(j * 8 * ldo * 2));
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            qg[qb] = q0 + 32 * qb + (lane & 31);
+            float dl = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl += (float)oraw[qb][ks][e] * (float)dof[qb][ks][e];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = (4 * qb + ks) * 28 / 8; i < (4 * qb + ks + 1) * 28 / 8; ++i) request(i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            dl += __shfl_xor(dl, 32, 64);
+            // for the dK / dV kernel, which runs after this one (every (row, head) belongs to exactly one wave)
+            if (h == 0) delta[((int64_t)b * H + head) * S + qg[qb]] = dl;
+            nlq[qb] = -(qb ? lq1 : lq0) * LOG2E;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pdl[qb][r] = -dl;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {  // from here on the fragments LIVE in accumulation registers (see attn_bwd_dkv2_kernel)
+                asm volatile("" : "=a"(qf[qb][ks]) : "0"(qf[qb][ks]));
+                asm volatile("" : "=a"(dof[qb][ks]) : "0"(dof[qb][ks]));
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[qb][db][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) dsu[i][k2] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) ktrh[sI][db][0] = ktrh[sI][db][1] = s16x4{0, 0, 0, 0};  // the first period's dQ products add 0 * 0
+        ring_cur = 0, ring_nxt = 16384, ring_n2 = 32768;
+        STAMPQ(1)
+
+        // ---- tile 0 is there for everybody (each wave waited for its own pieces above): row fragments of its first key block, transposed
+        // fragments of the same, S^T / dP^T of unit 0
+        ring_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) read_rows(0, 0, i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) read_tr(0, 0, i);
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_GUARD();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) sp_mfma(0, 0, 0, m);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+        STAMPQ(2)
+        // ---- the unmasked tiles: 0 .. nt - 2 ------------------------------------------------------------------------------------------------
+        int t = 0;
+        for (; t + 1 < nt; ++t) {
+            const int k0 = t * 64;
+            const int t3 = t + 3 < nt ? t + 3 : nt - 1;  // (a select)
+            MFMA_GUARD();
+            period(F_{}, F_{}, T_{}, U3, U0, U1, k0, [&](int m) __attribute__((always_inline)) { if (m < 8) read_rows(ring_cur, 1, m); }, none, [&]() __attribute__((always_inline)) { rows_landed(1); });
+            period(F_{}, F_{}, T_{}, U0, U1, U2, k0, [&](int m) __attribute__((always_inline)) { if (m < 8) read_tr(ring_cur, 1, m); }, none, [&]() __attribute__((always_inline)) { tr_landed(1); });
+            period(F_{}, T_{}, T_{}, U1, U2, U3, k0, [&](int m) __attribute__((always_inline)) { if (m < 8) read_rows(ring_nxt, 0, m); },
+                   [&](int m) __attribute__((always_inline)) { if (m >= 8) kvdma.piece(t3, ring_cur, m - 8); }, [&]() __attribute__((always_inline)) { rows_landed(0); });
+            period(F_{}, F_{}, T_{}, U2, U3, U0, k0, [&](int m) __attribute__((always_inline)) { if (m < 8) read_tr(ring_nxt, 0, m); }, none, [&]() __attribute__((always_inline)) { tr_landed(0); });
+            const unsigned c = ring_cur;
+            ring_cur = ring_nxt;
+            ring_nxt = ring_n2;
+            ring_n2 = c;
+        }
+        MFMA_DRAIN();
+        STAMPQ(3)
+        // ---- the diagonal tile, masked; no tile behind it.  Written as a second LOOP (of one trip): straight-line code here would be entered
+        // from the loop above or around it, the accumulation registers of the two ways in would meet at its entry, and hipcc moves them there.
+        // Two loops in sequence keep their registers (as in attn_bwd_dkv2_kernel).
+        for (; t < nt; ++t) {
+            const int k0 = t * 64;
+            MFMA_GUARD();
+            period(T_{}, F_{}, T_{}, U3, U0, U1, k0, [&](int m) __attribute__((always_inline)) { if (m < 8) read_rows(ring_cur, 1, m); }, none, [&]() __attribute__((always_inline)) { rows_landed(1); });
+            period(T_{}, F_{}, F_{}, U0, U1, U2, k0, [&](int m) __attribute__((always_inline)) { if (m < 8) read_tr(ring_cur, 1, m); }, none, [&]() __attribute__((always_inline)) { tr_landed(1); });
+            period(T_{}, F_{}, T_{}, U1, U2, U3, k0, none, none, [&]() __attribute__((always_inline)) {});
+            period(T_{}, F_{}, F_{}, U2, U3, U0, k0, none, none, [&]() __attribute__((always_inline)) {});
+        }
+        MFMA_DRAIN();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dq_mfma(U3.par, U3.kb, U3.qb, i);
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_DRAIN();
+        STAMPQ(4)
+        // ---- the store.  Every request of this wave has landed (table rows; the next item's rows; the tiles asked for beyond the last) ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ring_barrier();  // ... and every other wave's pieces of the table rows
+        f32x4 rcs[2][2][4];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int q = 32 * qb + (lane & 31);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+                    rcs[qb][db][gg] = *reinterpret_cast<const f32x4*>(smem + DQ2_ROPE + q * 256 + (((8 * db + 2 * gg + h) ^ (q & 15)) * 16));
+        }
+        // everybody has its table rows in registers and is done with the ring: the next item's requests may overwrite both
+        ring_barrier();
+        request_first_tiles(jn + 1);  // (behind the last item: its own once more — they land before the kernel ends, see below)
+        STAMPQ(5)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            bf16_t* drow = dqkv + (row0 + qg[qb]) * ld + (int64_t)head * HD;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(dq[qb][db][4 * gg + e] * 0.125f);
+                    // rope != NULL: the gradient leaves in pre-RoPE space (backward of the rotation fused here, saves a pass over dqkv)
+                    if (rope) v = unrope4(v, rcs[qb][db][gg]);
+                    *reinterpret_cast<bf16x4*>(drow + db * 32 + 8 * gg + 4 * h) = v;
+                }
+        }
+        STAMPQ(6)
+#ifdef DQ2_STAMP
+        if (it == DQ2_ITEMS - 1 && wave == 0) {  // DEBUG BUILD ONLY: overwrites the first floats of the item's first dq row
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                float* dbg = reinterpret_cast<float*>(dqkv + (row0 + q0) * ld + (int64_t)head * HD);
+                for (int i = 0; i < 7; ++i) dbg[i] = (float)stq_acc[i];
+                dbg[7] = (float)(__builtin_readcyclecounter() - stq_begin);
+                dbg[8] = (float)(__builtin_amdgcn_s_memrealtime() - stq_rt0);
+                dbg[9] = (float)g;
+            }
+        }
+#endif
+    }
+    // (the last item asked for its own rows once more: landed before its store — nothing of this workgroup is in flight towards LDS)
+}
+
+// =====================================================================================================================
 // backward: dK, dV
 // =====================================================================================================================
 // Workgroup = (b, kv head, 128-key group); wave w owns keys [key0 + 32 w, +32) and keeps their dK^T / dV^T in accumulators
@@ -889,14 +1366,6 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
 constexpr int DKV2_RING = 12;
 constexpr int DKV2_SB = 8192 + 256;
 constexpr int DKV2_MAX_STEPS = 2048;  // tiles per workgroup = (S / 32) * rep at most: S <= 16384 at rep = 4
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
-    bf16x2_ v;
-    v[0] = (bf16_t)a;
-    v[1] = (bf16_t)b;
-    return __builtin_bit_cast(unsigned, v);
-}
 
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
@@ -1358,8 +1827,18 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
                       int64_t seq, int n_heads, int n_kv, void* workspace, int64_t workspace_bytes, void* stream) {
     auto st = (hipStream_t)stream;
     const int rep = n_heads / n_kv, qpw = ANW / rep;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * n_kv * (seq / (32 * qpw)))), dim3(64 * ANW), 0, st, (const bf16_t*)qkv,
-                       ld, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_start, rope, positions, (int)seq, n_heads, n_kv);
+    // dQ: the pipelined one-wave-per-SIMD kernel (persistent workgroups of 8 query blocks) for plain causal rows of 4 query heads per kv
+    // head, where its workgroups fill the chip evenly (a whole number of rounds of 256, or many rounds); SSI_ATTN_DQ=1 (read per call:
+    // in-run A/B) keeps the round-1..3 kernel, =2 forces this one whatever the fill
+    const char* selq = getenv("SSI_ATTN_DQ");
+    const int64_t dq2_w = seq / 512, dq2_grid = batch * n_kv * dq2_w;
+    const bool dq2_fill = dq2_grid % 256 == 0 || dq2_grid >= 1024 || (selq && selq[0] == '2');
+    if (!doc_start && !positions && rep == 4 && seq % 512 == 0 && dq2_fill && !(selq && selq[0] == '1'))
+        hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3((unsigned)dq2_grid), dim3(256), 0, st, (const bf16_t*)qkv, ld, (const bf16_t*)out,
+                           (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, rope, (int)seq, n_heads, n_kv, (int)dq2_w);
+    else
+        hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * n_kv * (seq / (32 * qpw)))), dim3(64 * ANW), 0, st, (const bf16_t*)qkv,
+                           ld, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_start, rope, positions, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
     // dK / dV: the pipelined one-wave-per-SIMD kernel where its shape assumptions hold (256-key groups, an even number of tiles per group);
     // SSI_ATTN_DKV=1 (read per call: in-run A/B) keeps the round-1..3 kernel

@@ -569,6 +569,52 @@ def test_attention_dkv_pipelined_kernel_matches_the_128_key_kernel(ops, B, S, H,
     assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max()), "more than a bf16 step apart"
 
 
+@pytest.mark.parametrize("B,S,H,KV", [(1, 512, 4, 1), (3, 512, 8, 2), (2, 1024, 32, 8), (1, 2048, 8, 2), (8, 2048, 32, 8)])
+@pytest.mark.parametrize("fused_rope", [False, True])
+def test_attention_dq_pipelined_persistent_kernel_matches_the_round_1_kernel(ops, B, S, H, KV, fused_rope, monkeypatch):
+    """Round 4: dQ on the one-wave-per-SIMD pipelined kernel with persistent workgroups (8 query blocks of 64 per workgroup, the next block's
+    Q / dO / O rows and the RoPE table rows staged through LDS) against the round-1..3 kernel on the same inputs.  Same products, same order
+    of the sums over the key tiles; the exponent is one fma of the unscaled S (x log2(e)/8) where the old kernel scales Q by 1/8 first —
+    the same value — so the two agree to the last bits of the bf16 result on all but a few elements.  delta (which the dK / dV kernel reads)
+    and the dK / dV blocks must be IDENTICAL, the result reproducible.  S = 512: one workgroup per (batch, kv head) with all 8 blocks, B * KV
+    not a multiple of 8 (second case: the plain workgroup -> pair map); S = 1024 / 2048: 2 / 4 workgroups per pair in zig-zag groups; the last
+    case is the step's shape, the only one here the dispatcher picks by itself (the others are forced: SSI_ATTN_DQ=2)."""
+    from ssi import _lib
+    hd = 64
+    qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=81)
+    qkv[S // 2 + 3, :hd] *= 6.0
+    do = rnd(B * S, H * hd, dtype=torch.bfloat16, seed=82)
+    table = rnd(S + 8, hd // 2, 2, dtype=torch.float32, seed=83).to(DEV) if fused_rope else None   # any values do: the map is linear
+    prev = ops.set_impl(_lib.IMPL_MFMA)
+    try:
+        x, dout = qkv.to(DEV), do.to(DEV)
+        out = torch.empty(B * S, H * hd, dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+        ops.attn_fwd(x, out, lse, B, S, H, KV, hd)
+        res = {}
+        for sel in ("1", "2", "2") + (("0",) if (B, S) == (8, 2048) else ()):
+            monkeypatch.setenv("SSI_ATTN_DQ", sel)
+            d = torch.full_like(x, float("nan"))
+            delta = torch.full_like(lse, float("nan"))
+            ops.attn_bwd(x, out, dout, lse, d, delta, B, S, H, KV, hd, rope_table=table)
+            res.setdefault(sel, []).append((d.cpu().float(), delta.cpu()))
+    finally:
+        ops.set_impl(prev)
+    (old, dl_old), ((new, dl_new), (new2, _)) = res["1"][0], res["2"]
+    assert torch.isfinite(new).all()
+    assert torch.equal(new, new2), "not reproducible"
+    assert torch.equal(dl_old, dl_new), "delta differs"
+    assert torch.equal(old[:, H * hd:], new[:, H * hd:]), "the dK / dV blocks belong to the other kernel"
+    if "0" in res:
+        assert torch.equal(res["0"][0][0], new), "the dispatcher did not pick the pipelined kernel for the step's shape"
+    a, b = old[:, : H * hd], new[:, : H * hd]
+    assert not torch.equal(a, b), "the pipelined kernel did not run"
+    assert float((a != b).float().mean()) <= 0.02
+    rel = float((a - b).norm() / a.norm())
+    assert rel <= 3e-4, rel
+    assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max()), "more than a bf16 step apart"
+
+
 @pytest.mark.parametrize("B,S,H,KV,rows", [(2, 256, 4, 1, None), (1, 512, 8, 2, None), (2, 2048, 32, 8, None),
                                           (1, 1024, 8, 2, [[300, 37, 500, 187]]),
                                           (1, 11520, 32, 8, [[1807, 2038, 1909, 1924, 1500, 2048, 294]])])   # one long packed row: 720 workgroups, two heads each

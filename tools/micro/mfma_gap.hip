@@ -9,11 +9,14 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 #define VALU4 "v_mul_f32 %[x0], %[c], %[x0]\n v_exp_f32 %[x1], %[x1]\n v_mul_f32 %[x2], %[x2], %[x3]\n v_cvt_pk_bf16_f32 %[x4], %[x5], %[x6]\n"
+// the same arithmetic on two elements: scalar { fma fma exp exp mul mul cvt_pk } against packed { pk_fma exp exp pk_mul cvt_pk }
+#define VALU_S2 "v_fma_f32 %[p0], %[p0], %[c], %[q0]\n v_fma_f32 %[p1], %[p1], %[c], %[q0]\n v_exp_f32 %[q2], %[p0]\n v_exp_f32 %[q3], %[p1]\n v_mul_f32 %[q2], %[q2], %[p2]\n v_mul_f32 %[q3], %[q3], %[p3]\n v_cvt_pk_bf16_f32 %[x4], %[q2], %[q3]\n"
+#define VALU_P2 "v_pk_fma_f32 %[pp], %[pp], %[cc], %[qq]\n v_exp_f32 %[q2], %[p0]\n v_exp_f32 %[q3], %[p1]\n v_pk_mul_f32 %[rr], %[rr], %[pq]\n v_cvt_pk_bf16_f32 %[x4], %[q2], %[q3]\n"
 #define VOPS [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [x3] "+v"(x3), [x4] "+v"(x4), [x5] "+v"(x5), [x6] "+v"(x6)
 
 // MODE 0: A = v, B = a, C/D = v (S / dP products)   1: A = v, B = v, C/D = a (dV / dK products)   2: A = a, B = v, C/D = a
 // MODE 3: A = v, B = v, C/D = v                      VALU: vector instructions beside the MFMA or not
-template <int MODE, bool VALU> __global__ __launch_bounds__(256, 1) void k(const float* in, float* out, uint64_t* cyc, int iters) {
+template <int MODE, int VALU> __global__ __launch_bounds__(256, 1) void k(const float* in, float* out, uint64_t* cyc, int iters) {
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i)
         for (int r = 0; r < 16; ++r) acc[i][r] = in[threadIdx.x] + r + i;
@@ -25,6 +28,8 @@ template <int MODE, bool VALU> __global__ __launch_bounds__(256, 1) void k(const
         for (int i = 0; i < 4; ++i) asm volatile("" : "=a"(acc[i]) : "0"(acc[i]));
     float x0 = in[threadIdx.x], x1 = x0 * 0.5f, x2 = x0 + 2, x3 = x0 + 3, x4 = 0, x5 = x0 + 5, x6 = x0 + 6;
     const float c = -1.44269504f;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    f32x2 pp = {x0, x1}, rr = {x2, x3}, cc = {c, c}, qq = {x5, x6}, pp2 = {x1, x0}, rr2 = {x3, x2};
     const uint64_t t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -33,12 +38,17 @@ template <int MODE, bool VALU> __global__ __launch_bounds__(256, 1) void k(const
             if (MODE == 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[g & 3]) : "v"(av), "v"(bv));
             if (MODE == 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[g & 3]) : "a"(aa), "v"(bv));
             if (MODE == 3) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(av), "v"(bv));
-            if (VALU) asm volatile(VALU4 : VOPS : [c] "v"(c));
+            // MODE 4: no MFMA at all (an epilogue: the matrix pipe idle)
+            if (VALU == 1) asm volatile(VALU4 : VOPS : [c] "v"(c));
+            if (VALU == 2) asm volatile(VALU_S2 : [p0] "+v"(x0), [p1] "+v"(x1), [q2] "+v"(x2), [q3] "+v"(x3), [x4] "+v"(x4) : [c] "v"(c), [q0] "v"(x5), [p2] "v"(x5), [p3] "v"(x6));
+            if (VALU == 3) asm volatile(VALU_P2 : [pp] "+v"(pp), [rr] "+v"(rr), [q2] "+v"(x2), [q3] "+v"(x3), [x4] "+v"(x4) : [cc] "v"(cc), [qq] "v"(qq), [pq] "v"(qq), [p0] "v"(x0), [p1] "v"(x1));
+            if (VALU == 4) asm volatile("v_pk_fma_f32 %[pp], %[pp], %[cc], %[qq]\n v_pk_mul_f32 %[rr], %[rr], %[qq]\n v_pk_fma_f32 %[p2], %[p2], %[cc], %[qq]\n v_pk_mul_f32 %[r2], %[r2], %[qq]\n" : [pp] "+v"(pp), [rr] "+v"(rr), [p2] "+v"(pp2), [r2] "+v"(rr2) : [cc] "v"(cc), [qq] "v"(qq));
+            if (VALU == 5) asm volatile("v_fma_f32 %[p0], %[p0], %[c], %[q0]\n v_mul_f32 %[p1], %[p1], %[q0]\n v_fma_f32 %[q2], %[q2], %[c], %[q0]\n v_mul_f32 %[q3], %[q3], %[q0]\n" : [p0] "+v"(x0), [p1] "+v"(x1), [q2] "+v"(x2), [q3] "+v"(x3) : [c] "v"(c), [q0] "v"(x5));
         }
     }
     const uint64_t t1 = __builtin_readcyclecounter();
     asm volatile("s_nop 15\n s_nop 15");
-    float s = x0 + x1 + x2 + x3 + x4 + x5 + x6;
+    float s = x0 + x1 + x2 + x3 + x4 + x5 + x6 + pp[0] + pp[1] + rr[0] + rr[1] + pp2[0] + pp2[1] + rr2[0] + rr2[1];
     for (int i = 0; i < 4; ++i)
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -59,11 +69,19 @@ template <typename K> double run(K kern, const char* name) {
     return per;
 }
 int main() {
-    run(k<0, false>, "A=v B=a C/D=v, MFMA alone");
-    run(k<1, false>, "A=v B=v C/D=a, MFMA alone");
-    run(k<0, true>, "A=v B=a C/D=v, + mul exp mul cvt_pk");
-    run(k<1, true>, "A=v B=v C/D=a, + mul exp mul cvt_pk");
-    run(k<2, true>, "A=a B=v C/D=a, + mul exp mul cvt_pk");
-    run(k<3, true>, "A=v B=v C/D=v, + mul exp mul cvt_pk");
+    run(k<0, 0>, "A=v B=a C/D=v, MFMA alone");
+    run(k<1, 0>, "A=v B=v C/D=a, MFMA alone");
+    run(k<0, 1>, "A=v B=a C/D=v, + mul exp mul cvt_pk");
+    run(k<1, 1>, "A=v B=v C/D=a, + mul exp mul cvt_pk");
+    run(k<2, 1>, "A=a B=v C/D=a, + mul exp mul cvt_pk");
+    run(k<3, 1>, "A=v B=v C/D=v, + mul exp mul cvt_pk");
+    run(k<0, 2>, "A=v B=a C/D=v, + fma fma exp exp mul mul cvt_pk");
+    run(k<0, 3>, "A=v B=a C/D=v, + pk_fma exp exp pk_mul cvt_pk");
+    run(k<0, 4>, "A=v B=a C/D=v, + pk_fma pk_mul pk_fma pk_mul");
+    run(k<0, 5>, "A=v B=a C/D=v, + fma mul fma mul");
+    run(k<4, 4>, "no MFMA: pk_fma pk_mul pk_fma pk_mul (8 elements)");
+    run(k<4, 5>, "no MFMA: fma mul fma mul (4 elements)");
+    run(k<4, 2>, "no MFMA: fma fma exp exp mul mul cvt_pk");
+    run(k<4, 3>, "no MFMA: pk_fma exp exp pk_mul cvt_pk");
     return 0;
 }
