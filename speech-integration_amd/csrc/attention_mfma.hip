@@ -630,11 +630,11 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_bwd_dq_kernel
 //
 // With 400 registers per wave a CU holds ONE workgroup, so whatever an item does before and behind its tiles — waiting for its operands,
 // converting them, storing dQ — is time the matrix pipe stands still: ~19 000 cycles per item against ~2 350 per tile and 16.5 tiles per item
-// when every item was a workgroup (profiles/r04_dq2_stamps.txt).  Hence the workgroups are PERSISTENT: a workgroup walks DQ2_ITEMS = 8 query
-// blocks of one (batch, kv head) — blocks g, 2W-1-g, 2W+g, 4W-1-g, ... of the S/64, W = S/512 workgroups per pair, every workgroup the same
-// number of tiles — and the Q, dO and O rows of the NEXT item are requested (LDS-DMA, whole 128-B lines, into per-wave images: no barrier)
+// when every item was a workgroup (profiles/r04_dq2_stamps.txt).  Hence the workgroups are PERSISTENT: a workgroup walks DQ2_ITEMS = 8 (4, 2 for
+// small launches) query blocks of one (batch, kv head) — blocks g, 2W-1-g, 2W+g, 4W-1-g, ... of the S/64, W = S/64/DQ2_ITEMS workgroups per
+// pair, every workgroup the same number of tiles — and the Q, dO and O rows of the NEXT item are requested (LDS-DMA, whole 128-B lines, into per-wave images: no barrier)
 // while the current item computes; its lse one item ahead into registers; the RoPE table rows for the store into LDS as well.
-constexpr int DQ2_RING = 3, DQ2_ITEMS = 8;
+constexpr int DQ2_RING = 3;
 constexpr int DQ2_STAGE = DQ2_RING * 16384;            // per wave: [Q | dO | O][64][64] bf16 images of the item's rows of its head
 constexpr int DQ2_ROPE = DQ2_STAGE + 4 * 3 * 8192;     // [64 queries][64] fp32 table rows, 16-B chunks XOR (row & 15)
 constexpr int DQ2_LDS = DQ2_ROPE + 64 * 256;           // 160 KiB: all of a CU's LDS
@@ -683,6 +683,7 @@ constexpr Dq2Plan dq2_make_plan() {
 }
 constexpr Dq2Plan DQ2_PLAN = dq2_make_plan();
 
+template <int DQ2_ITEMS>  // query blocks per workgroup: 8, 4 or 2 (the host takes the largest that fills the chip in whole rounds)
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ out,
                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                               float* __restrict__ delta, bf16_t* __restrict__ dqkv,
@@ -1827,15 +1828,27 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
                       int64_t seq, int n_heads, int n_kv, void* workspace, int64_t workspace_bytes, void* stream) {
     auto st = (hipStream_t)stream;
     const int rep = n_heads / n_kv, qpw = ANW / rep;
-    // dQ: the pipelined one-wave-per-SIMD kernel (persistent workgroups of 8 query blocks) for plain causal rows of 4 query heads per kv
-    // head, where its workgroups fill the chip evenly (a whole number of rounds of 256, or many rounds); SSI_ATTN_DQ=1 (read per call:
-    // in-run A/B) keeps the round-1..3 kernel, =2 forces this one whatever the fill
+    // dQ: the pipelined one-wave-per-SIMD kernel (persistent workgroups of 8, 4 or 2 query blocks: the largest count whose workgroups fill
+    // the chip in whole rounds of 256, or in many rounds) for plain causal rows of 4 query heads per kv head; SSI_ATTN_DQ=1 (read per call:
+    // in-run A/B) keeps the round-1..3 kernel, =2 forces this one (8 blocks per workgroup if S allows, else 4, 2) whatever the fill
     const char* selq = getenv("SSI_ATTN_DQ");
-    const int64_t dq2_w = seq / 512, dq2_grid = batch * n_kv * dq2_w;
-    const bool dq2_fill = dq2_grid % 256 == 0 || dq2_grid >= 1024 || (selq && selq[0] == '2');
-    if (!doc_start && !positions && rep == 4 && seq % 512 == 0 && dq2_fill && !(selq && selq[0] == '1'))
-        hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3((unsigned)dq2_grid), dim3(256), 0, st, (const bf16_t*)qkv, ld, (const bf16_t*)out,
-                           (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, rope, (int)seq, n_heads, n_kv, (int)dq2_w);
+    int dq2_items = 0;
+    if (!doc_start && !positions && rep == 4 && seq % 128 == 0 && !(selq && selq[0] == '1')) {
+        const int64_t nqb = seq / 64;
+        for (int it = 8; it >= 2 && !dq2_items; it >>= 1) {
+            if (nqb % it) continue;
+            const int64_t grid = batch * n_kv * (nqb / it);
+            if (grid % 256 == 0 || grid >= 1024) dq2_items = it;
+        }
+        if (!dq2_items && selq && selq[0] == '2') dq2_items = nqb % 8 == 0 ? 8 : nqb % 4 == 0 ? 4 : 2;
+    }
+    if (dq2_items) {
+        const int w = (int)(seq / 64 / dq2_items);
+        const dim3 grid((unsigned)(batch * n_kv * w));
+        auto kern = dq2_items == 8 ? attn_bwd_dq2_kernel<8> : dq2_items == 4 ? attn_bwd_dq2_kernel<4> : attn_bwd_dq2_kernel<2>;
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, (const bf16_t*)qkv, ld, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv,
+                           rope, (int)seq, n_heads, n_kv, w);
+    }
     else
         hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * n_kv * (seq / (32 * qpw)))), dim3(64 * ANW), 0, st, (const bf16_t*)qkv,
                            ld, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_start, rope, positions, (int)seq, n_heads, n_kv);

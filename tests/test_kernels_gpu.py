@@ -569,7 +569,8 @@ def test_attention_dkv_pipelined_kernel_matches_the_128_key_kernel(ops, B, S, H,
     assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max()), "more than a bf16 step apart"
 
 
-@pytest.mark.parametrize("B,S,H,KV", [(1, 512, 4, 1), (3, 512, 8, 2), (2, 1024, 32, 8), (1, 2048, 8, 2), (8, 2048, 32, 8)])
+@pytest.mark.parametrize("B,S,H,KV", [(1, 512, 4, 1), (3, 512, 8, 2), (2, 1024, 32, 8), (1, 2048, 8, 2), (8, 2048, 32, 8),
+                                      (2, 128, 8, 2), (1, 256, 4, 1), (3, 384, 4, 1), (2, 2048, 32, 8)])
 @pytest.mark.parametrize("fused_rope", [False, True])
 def test_attention_dq_pipelined_persistent_kernel_matches_the_round_1_kernel(ops, B, S, H, KV, fused_rope, monkeypatch):
     """Round 4: dQ on the one-wave-per-SIMD pipelined kernel with persistent workgroups (8 query blocks of 64 per workgroup, the next block's
@@ -577,8 +578,10 @@ def test_attention_dq_pipelined_persistent_kernel_matches_the_round_1_kernel(ops
     of the sums over the key tiles; the exponent is one fma of the unscaled S (x log2(e)/8) where the old kernel scales Q by 1/8 first —
     the same value — so the two agree to the last bits of the bf16 result on all but a few elements.  delta (which the dK / dV kernel reads)
     and the dK / dV blocks must be IDENTICAL, the result reproducible.  S = 512: one workgroup per (batch, kv head) with all 8 blocks, B * KV
-    not a multiple of 8 (second case: the plain workgroup -> pair map); S = 1024 / 2048: 2 / 4 workgroups per pair in zig-zag groups; the last
-    case is the step's shape, the only one here the dispatcher picks by itself (the others are forced: SSI_ATTN_DQ=2)."""
+    not a multiple of 8 (second case: the plain workgroup -> pair map); S = 1024 / 2048: 2 / 4 workgroups per pair in zig-zag groups; the
+    fifth case is the step's shape; S = 128, 256, 384: 2, 4 and 2 blocks per workgroup (a single pair of blocks; 3 workgroups per pair); the
+    last is the reference's default SFT micro-batch, 2 x 2048, where the dispatcher takes 2 blocks per workgroup (256 workgroups).  Those two
+    the dispatcher picks by itself, the others are forced (SSI_ATTN_DQ=2)."""
     from ssi import _lib
     hd = 64
     qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=81)
@@ -592,7 +595,7 @@ def test_attention_dq_pipelined_persistent_kernel_matches_the_round_1_kernel(ops
         lse = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
         ops.attn_fwd(x, out, lse, B, S, H, KV, hd)
         res = {}
-        for sel in ("1", "2", "2") + (("0",) if (B, S) == (8, 2048) else ()):
+        for sel in ("1", "2", "2") + (("0",) if (B, S) in ((8, 2048), (2, 2048)) else ()):
             monkeypatch.setenv("SSI_ATTN_DQ", sel)
             d = torch.full_like(x, float("nan"))
             delta = torch.full_like(lse, float("nan"))

@@ -55,6 +55,41 @@ template <int MODE, int VALU> __global__ __launch_bounds__(256, 1) void k(const 
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// The persistent GEMM's stream: v_mfma_f32_16x16x32_bf16 (16 cycles of matrix pipe each) on 16 independent accumulators in accumulation
+// registers, NV vector instructions (mul / fma on 8 independent registers) behind every MFMA: how many fit before the stream slows down?
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int NV, bool TRANS> __global__ __launch_bounds__(256, 1) void k16(const float* in, float* out, uint64_t* cyc, int iters) {
+    f32x4 acc[16];
+    for (int i = 0; i < 16; ++i)
+        for (int r = 0; r < 4; ++r) acc[i][r] = in[threadIdx.x] + r + i;
+    for (int i = 0; i < 16; ++i) asm volatile("" : "=a"(acc[i]) : "0"(acc[i]));
+    u32x4 av = {threadIdx.x, 1u, 2u, 3u}, bv = {5u, threadIdx.x, 7u, 9u};
+    float x[8];
+    for (int i = 0; i < 8; ++i) x[i] = in[threadIdx.x] + i;
+    const float c = 1.0001f;
+    const uint64_t t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[g]) : "v"(av), "v"(bv));
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int r = (g * NV + v) & 7;
+                if (TRANS && v == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(x[r]));
+                else asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[r]) : "v"(c));
+            }
+        }
+    }
+    const uint64_t t1 = __builtin_readcyclecounter();
+    asm volatile("s_nop 15\n s_nop 15");
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += x[i];
+    for (int i = 0; i < 16; ++i)
+        for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = (t1 - t0) / 2;  // (run() divides by 8 gaps per iteration: 16 here)
+}
+
 template <typename K> double run(K kern, const char* name) {
     float *in, *out; uint64_t* cyc;
     const int iters = 2000;
@@ -83,5 +118,11 @@ int main() {
     run(k<4, 5>, "no MFMA: fma mul fma mul (4 elements)");
     run(k<4, 2>, "no MFMA: fma fma exp exp mul mul cvt_pk");
     run(k<4, 3>, "no MFMA: pk_fma exp exp pk_mul cvt_pk");
+    run(k16<0, false>, "16x16x32 stream, MFMA alone");
+    run(k16<1, false>, "16x16x32 stream + 1 fma per MFMA");
+    run(k16<2, false>, "16x16x32 stream + 2 fma per MFMA");
+    run(k16<3, false>, "16x16x32 stream + 3 fma per MFMA");
+    run(k16<1, true>, "16x16x32 stream + 1 exp per MFMA");
+    run(k16<2, true>, "16x16x32 stream + exp fma per MFMA");
     return 0;
 }
