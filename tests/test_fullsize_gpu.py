@@ -590,4 +590,11 @@ def test_full_size_model_on_long_rows(name, n_dsus, B, S, packed):
         assert abs(lp - l1) > 1e-5 * abs(l1)                       # documents no longer isolated -> a different loss
         one_doc = dict(plain, input_pos=torch.arange(S, device=DEV).expand(B, S).contiguous())
         lo, go = run(one_doc)
-        assert lo == lp and torch.equal(go, gp)                    # one document per row == plain causal attention, bit for bit
+        # one document per row == plain causal attention: the forward bit for bit (one kernel, the document bounds change nothing); the
+        # backward to what a different order of the fp32 sums does to a 16-layer bf16 backward — rows that come with positions run the
+        # round-1 dQ / dK / dV kernels, plain rows the pipelined ones where their workgroups fill the chip (same products; 1e-4 relative
+        # apart per kernel call, 0.3 % of the bf16 results a step apart).  Measured 9.1e-3 on the flat gradient; the bf16 model is 4.4e-2
+        # from the fp32 oracle at this shape (TOL_GRAD_BF16), a wrong kernel O(1)
+        assert lo == lp
+        rel = float((go.float() - gp.float()).norm() / gp.float().norm())
+        assert rel <= 2.5e-2, rel
