@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
         }
         // everybody has its table rows in registers and is done with the ring: the next item's requests may overwrite both
         ring_barrier();
-        request_first_tiles(jn + 1);  // (behind the last item: its own once more — they land before the kernel ends, see below)
+        request_first_tiles(jn + 1);  // (behind the last item: its own once more — waited for at the end of the kernel)
         STAMPQ(5)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -1064,7 +1064,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
         }
 #endif
     }
-    // (the last item asked for its own rows once more: landed before its store — nothing of this workgroup is in flight towards LDS)
+    // The last item asked for its own rows once more (landed before its store) — and for its first three tiles once more, in front of its
+    // store: nothing of this workgroup may be in flight towards LDS when it ends (the LDS goes to the next workgroup on this CU).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // =====================================================================================================================
