@@ -3,6 +3,7 @@
 // end of the wait, all 256 CUs storing at once (as the persistent GEMM's epilogues do).
 //   MAP 0: the GEMM epilogue's map — a store covers 8 rows x 128 B (whole lines), rows ldc apart
 //   MAP 1: one contiguous KiB per store (lane * 16)
+//   MAP 2 / 3 / 4: a store covers 4 rows x 256 B / 2 rows x 512 B / 16 rows x 64 B of the tile
 //   AUX  : cache-policy bits of the buffer store (0 default, 2 nt, 16 sc1, 17 sc0 sc1)
 // build: hipcc -O3 --offload-arch=gfx950 tools/micro/store_rate.hip -o tools/micro/store_rate
 #include <hip/hip_runtime.h>
@@ -23,7 +24,10 @@ template <int MAP, int AUX, int GAP> __global__ __launch_bounds__(256, 1) void k
         for (int i = 0; i < 32; ++i) {
             int off;
             if (MAP == 0) off = (int)(tile + ((wave >> 1) * 128 + (i >> 1) * 8 + (lane & 7)) * ldc_bytes + (wave & 1) * 256 + (i & 1) * 128 + (lane >> 3) * 16);
-            else off = (int)(tile + ((wave * 32 + i) * 2) * ldc_bytes + lane * 16);   // (two rows' worth, contiguous: a 1-KiB run)
+            else if (MAP == 1) off = (int)(tile + ((wave * 32 + i) * 2) * ldc_bytes + lane * 16);   // (two rows' worth, contiguous: a 1-KiB run)
+            else if (MAP == 2) off = (int)(tile + (wave * 64 + (i >> 1) * 4 + (lane >> 4)) * ldc_bytes + (i & 1) * 256 + (lane & 15) * 16);
+            else if (MAP == 3) off = (int)(tile + (wave * 64 + i * 2 + (lane >> 5)) * ldc_bytes + (lane & 31) * 16);
+            else off = (int)(tile + ((wave >> 1) * 128 + (i >> 2) * 16 + (lane & 15)) * ldc_bytes + (wave & 1) * 256 + (i & 3) * 64 + (lane >> 4) * 16);
             __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, AUX);
             if (GAP) __builtin_amdgcn_s_sleep(GAP);
         }
@@ -47,6 +51,10 @@ int main() {
     run(k<0, 0, 0>, "GEMM map, default policy, 32 CUs (one per 8)", 32);
     run(k<0, 0, 0>, "GEMM map, default policy, 1 CU", 1);
     run(k<1, 0, 0>, "contiguous KiB per store, default, 256 CUs", 256);
+    run(k<2, 0, 0>, "4 rows x 256 B per store, default, 256 CUs", 256);
+    run(k<3, 0, 0>, "2 rows x 512 B per store, default, 256 CUs", 256);
+    run(k<4, 0, 0>, "16 rows x 64 B per store, default, 256 CUs", 256);
+    run(k<0, 0, 0>, "GEMM map, default policy, 256 CUs (again)", 256);
     run(k<0, 2, 0>, "GEMM map, nt, 256 CUs", 256);
     run(k<0, 16, 0>, "GEMM map, sc1, 256 CUs", 256);
     run(k<0, 17, 0>, "GEMM map, sc0 sc1, 256 CUs", 256);
