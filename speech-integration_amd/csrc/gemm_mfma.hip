@@ -20,7 +20,6 @@
 #include "common_hip.h"
 #include <atomic>
 #include <type_traits>
-#include <utility>
 
 int ssi_get_impl();
 
@@ -517,8 +516,6 @@ constexpr unsigned BUF_RSRC_DW3 = 0x00020000u;  // raw buffer, 32-bit data forma
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, BUF_RSRC_DW3);
 }
-
-template <int... M, typename F> __device__ __forceinline__ void nt4_static_for(std::integer_sequence<int, M...>, F&& f) { (f(M), ...); }
 
 // A_COL / B_COL: false = the operand is k-contiguous in memory, true = k-strided (its tile is a [64 k][256 columns] image read
 //      back with ds_read_b64_tr_b16, as in the 8-wave kernel).  NT = (false, false), NN = (false, true: data gradients against
@@ -1271,271 +1268,6 @@ int launch_nt4(int tiles_m, int tiles_n, int64_t K, const void* A, int64_t lda, 
     return SSI_OK;
 }
 
-// =====================================================================================================================
-// Persistent NT GEMM with 256 x 128 workgroup tiles (128 x 64 per wave = 128 accumulation registers) — PROTOTYPE of the two-accumulator-set
-// design: PINGPONG = false runs every tile's epilogue behind its K-loop like gemm_nt4dma_kernel (measures what the
-// smaller tile costs the main loop); PINGPONG = true alternates two accumulator sets and works a finished set's epilogue off under the
-// next tile's K-steps.  k-contiguous operands, plain epilogue (C = alpha * A B^T), static tile order, K a multiple of 128.
-// Same K order per output element as gemm_nt4dma_kernel: bit-identical results.
-// =====================================================================================================================
-constexpr int PP_BN = 128, PP_WN = 64;
-constexpr int PP_BTILE = PP_BN * BK * 2;                            // 16 KiB per B buffer
-constexpr int PP_LDS_BYTES = 3 * TILE_BYTES + 3 * PP_BTILE + 16;   // [A0 | A1 | A2 | B0 | B1 | B2] = 144 KiB: a ring of THREE K-steps
-
-// With 64 MFMAs per K-step (half of gemm_nt4dma_kernel's 128) two LDS buffers would mean two barriers per 64 MFMAs and half the lead for the
-// LDS-DMA pieces (measured: 8.2 ms against 6.4 for the LM-head shape).  Three buffers: the pieces of K-step j go out between the barrier of
-// K-step j-3 and the end of phase A of K-step j-2 (79 MFMAs before they are needed), the buffer they land in was last read in K-step j-3,
-// and ONE barrier per K-step (arrival of K-step j+1 = everybody done with the buffer of K-step j-2) is all the synchronisation left.  The
-// buffer of a K-step is a runtime offset (k mod 3): four address adds per K-step.
-template <bool PINGPONG>
-__global__ __launch_bounds__(256, 1) void gemm_nt4pp_kernel(int tiles_m, int tiles_n, int64_t K, const bf16_t* __restrict__ A, int64_t lda,
-                                                            const bf16_t* __restrict__ B, int64_t ldb, bf16_t* __restrict__ C, int64_t ldc,
-                                                            float alpha) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntiles = tiles_m * tiles_n, G = (int)gridDim.x, nk = (int)(K / BK);
-    // static tile order of gemm_nt4dma_kernel: every XCD walks its contiguous span of the tile sequence, workgroup b / 8 of the XCD first
-    const int xcd = (int)blockIdx.x & 7, span_q = ntiles >> 3, span_r = ntiles & 7;
-    auto span_len = [&](int x) { return span_q + (x < span_r ? 1 : 0); };
-    auto span_lo = [&](int x) { return x < span_r ? x * (span_q + 1) : span_r * (span_q + 1) + (x - span_r) * span_q; };
-    int my_idx = (int)blockIdx.x >> 3;
-    auto receive_tile = [&]() -> int {
-        my_idx += G >> 3;
-        return ((G & 7) == 0 && my_idx < span_len(xcd)) ? span_lo(xcd) + my_idx : -1;
-    };
-    int cur = my_idx < span_len(xcd) ? span_lo(xcd) + my_idx : -1;
-    if (cur < 0) return;
-    int nxt = receive_tile();
-
-    f32x4 acc[PINGPONG ? 2 : 1][4][8];  // [set][j (n-tile)][i (m-tile)]
-
-    // ---- load side -----------------------------------------------------------------------------------------------------------------------
-    int lkt = 0;
-    const bf16_t* baseA = A;
-    const bf16_t* baseB = B;
-    auto set_load_tile = [&](int t) {
-        int tm, tn;
-        tile_from_t(t, tiles_m, tiles_n, tm, tn);
-        baseA = A + (int64_t)tm * BM * lda;
-        baseB = B + (int64_t)tn * PP_BN * ldb;
-    };
-    auto advance = [&]() {
-        if (++lkt == nk) {
-            lkt = 0;
-            if (nxt >= 0) set_load_tile(nxt);  // after the last tile: keep re-fetching valid memory, never consumed
-        }
-    };
-    const int dofA = (int)(((tid >> 3) * lda + (((tid & 7) ^ ((tid >> 4) & 7)) * 8)) * 2);
-    const int dofB = (int)(((tid >> 3) * ldb + (((tid & 7) ^ ((tid >> 4) & 7)) * 8)) * 2);
-    typedef __attribute__((address_space(3))) char lds_c;
-    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)smem + (unsigned)wave * 1024u);
-    auto rsrc_words = [&](const bf16_t* base) {
-        const uint64_t a = (uint64_t)(uintptr_t)base;
-        u32x4 r;
-        r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
-        r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-        r[2] = 0x7fffffffu;
-        r[3] = BUF_RSRC_DW3;
-        return r;
-    };
-    u32x4 rsA, rsB;           // buffer resources of the K-step being fetched
-    unsigned fill_a, fill_b;  // LDS byte offsets (A and B part) of the buffer it goes to
-    auto dma_src = [&]() { rsA = rsrc_words(baseA + lkt * BK); rsB = rsrc_words(baseB + lkt * BK); };
-    // piece d: 0..7 = A rows d*32 .. +31, 8..11 = B rows (d-8)*32 .. +31 of the K-step being fetched
-    auto dma_m0 = [&](int d) {
-        const unsigned dst = lds_wave + (d < 8 ? fill_a + (unsigned)(d * 4096) : fill_b + (unsigned)((d - 8) * 4096));
-        asm volatile("s_mov_b32 m0, %0" ::"s"(dst) : "memory");
-    };
-    auto dma_go = [&](int d) {
-        if (d < 8) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(dofA), "s"(rsA), "s"((int)(d * 32 * lda * 2)) : "memory");
-        else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(dofB), "s"(rsB), "s"((int)((d - 8) * 32 * ldb * 2)) : "memory");
-    };
-    // fragment addresses: lane part per (operand, k-half) — the swizzle term ((row >> 1) & 7) does not depend on the 16-row block — plus the
-    // buffer's offset, plus 2 KiB per 16-row block as an immediate
-    int laneA[2], laneB[2];
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-        const int ra = wm * NT4_WM + (lane & 15), rb = wn * PP_WN + (lane & 15);
-        laneA[kh] = ra * 128 + (((kh * 4 + (lane >> 4)) ^ ((ra >> 1) & 7)) * 16);
-        laneB[kh] = rb * 128 + (((kh * 4 + (lane >> 4)) ^ ((rb >> 1) & 7)) * 16);
-    }
-    bf16x8 F0A[8], F0B[4], F1A[8], F1B[4];  // a whole K-step of fragments: k-half 0, k-half 1
-    auto rd = [&](const char* base, int blk) { return *reinterpret_cast<const bf16x8*>(base + blk * 2048); };
-
-    // 32 MFMAs: every accumulator tile of set `set` once, A fragment outer; extra(m) is issued right after MFMA m and pinned there
-    auto phase = [&](auto set_c, const bf16x8 (&fa)[8], const bf16x8 (&fb)[4], bool zero_c, auto extra) {
-        constexpr int SET = decltype(set_c)::value;
-        auto step = [&](int m) __attribute__((always_inline)) {
-            const int i = m >> 2, j = m & 3;
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[SET][j][i]) : "v"(fb[j]), "v"(fa[i]));
-            extra(m);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        (void)zero_c;
-        nt4_static_for(std::make_integer_sequence<int, 32>{}, step);
-    };
-    unsigned ring_a[3] = {0u, (unsigned)TILE_BYTES, 2u * TILE_BYTES};  // A part of the buffers of K-steps k, k+1, k+2 (k = the one computed)
-    unsigned ring_b[3] = {3u * TILE_BYTES, 3u * TILE_BYTES + PP_BTILE, 3u * TILE_BYTES + 2u * PP_BTILE};
-    // one K-step on accumulator set SET; hookA / hookB(m): extra work behind MFMA m of the two phases
-    auto kstep = [&](auto set_c, auto hookA, auto hookB) {
-        const char* a1 = smem + ring_a[0] + laneA[1];
-        const char* b1 = smem + ring_b[0] + laneB[1];
-        const char* a0n = smem + ring_a[1] + laneA[0];
-        const char* b0n = smem + ring_b[1] + laneB[0];
-        // phase A: products on k-half 0; k-half 1 of this K-step is read; pieces 6 .. 11 of K-step +2 (its buffer was last read two K-steps ago)
-        phase(set_c, F0A, F0B, false, [&](int m) {
-            if (m < 12) {
-                if (m < 4) F1B[m] = rd(b1, m); else F1A[m - 4] = rd(a1, m - 4);
-            }
-            if (m >= 2 && m <= 27 && (m - 2) % 5 == 0) dma_m0(6 + (m - 2) / 5);
-            if (m >= 3 && m <= 28 && (m - 3) % 5 == 0) dma_go(6 + (m - 3) / 5);
-            hookA(m);
-        });
-        advance();
-        phase(set_c, F1A, F1B, false, [&](int m) {
-            if (m == 11) {
-                // K-step +1 has landed for this wave (the 12 pieces of K-step +2 issued since may still be in flight) and, with the barrier,
-                // for every wave; every wave has also read all it needs of this K-step's buffer: the pieces of K-step +3 may go there
-                asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                dma_src();
-                fill_a = ring_a[0];
-                fill_b = ring_b[0];
-            }
-            if (m >= 13 && m <= 28 && (m - 13) % 3 == 0) dma_m0((m - 13) / 3);  // 13, 16, ..., 28: pieces 0 .. 5 of K-step +3
-            if (m >= 14 && m <= 29 && (m - 14) % 3 == 0) dma_go((m - 14) / 3);
-            if (m >= 12 && m <= 29 && (m - 13) % 3 != 0) {  // k-half 0 of the next K-step: 12 reads (12, 14, 15, 17, 18, ..., 29)
-                const int r = (m - 12) - (m - 11) / 3;
-                if (r < 4) F0B[r] = rd(b0n, r); else F0A[r - 4] = rd(a0n, r - 4);
-            }
-            hookB(m);
-        });
-        const unsigned ta = ring_a[0], tb = ring_b[0];  // the ring moves on
-        ring_a[0] = ring_a[1]; ring_a[1] = ring_a[2]; ring_a[2] = ta;
-        ring_b[0] = ring_b[1]; ring_b[1] = ring_b[2]; ring_b[2] = tb;
-    };
-    auto nohook = [&](int) {};
-
-    // ---- prologue: K-steps 0 and 1 of the first tile whole, pieces 0 .. 5 of K-step 2 (the rest goes out in phase A of K-step 0) -------
-    set_load_tile(cur);
-    for (int b = 0; b < 2; ++b) {
-        dma_src();
-        fill_a = ring_a[b];
-        fill_b = ring_b[b];
-#pragma unroll
-        for (int d = 0; d < 12; ++d) {
-            dma_m0(d);
-            asm volatile("s_nop 1" ::: "memory");
-            dma_go(d);
-        }
-        advance();
-    }
-    dma_src();
-    fill_a = ring_a[2];
-    fill_b = ring_b[2];
-#pragma unroll
-    for (int d = 0; d < 6; ++d) {
-        dma_m0(d);
-        asm volatile("s_nop 1" ::: "memory");
-        dma_go(d);
-    }
-    asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");  // K-step 0 is in LDS
-    {
-        const char* a0 = smem + ring_a[0] + laneA[0];
-        const char* b0 = smem + ring_b[0] + laneB[0];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) F0B[r] = rd(b0, r);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) F0A[r] = rd(a0, r);
-    }
-
-    using B0_ = std::integral_constant<int, 0>;
-    const int g = lane >> 4;
-    const int lane_row = lane & 7, lane_col = ((lane >> 3) & 1) * 32 + (g & 1) * 16 + (g >> 1) * 8;
-    auto zero_acc = [&](auto set_c) {
-        constexpr int SET = decltype(set_c)::value;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                acc[SET][j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                asm volatile("" : "+a"(acc[SET][j][i]));
-            }
-        asm volatile("s_nop 7" ::: "memory");  // (the asm MFMAs are opaque to the hazard recogniser: a gap behind the writes)
-    };
-    // epilogue pieces of gemm_nt4dma_kernel (see there): pair -> 8 consecutive columns per lane, duo -> whole 128-B lines per store
-    auto pair = [&](auto set_c, int i, int ja, int jb) {
-        constexpr int SET = decltype(set_c)::value;
-        bf16x4 x, y;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float fx, fy;
-            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(fx) : "a"(acc[SET][ja][i][r]));
-            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(fy) : "a"(acc[SET][jb][i][r]));
-            x[r] = (bf16_t)(fx * alpha);
-            y[r] = (bf16_t)(fy * alpha);
-        }
-        const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
-        const auto s0 = __builtin_amdgcn_permlane16_swap(xu[0], yu[0], false, false);
-        const auto s1 = __builtin_amdgcn_permlane16_swap(xu[1], yu[1], false, false);
-        u32x4 o;
-        o[0] = s0[0]; o[1] = s1[0]; o[2] = s0[1]; o[3] = s1[1];
-        return o;
-    };
-    auto duo = [&](auto set_c, int i, u32x4& lo, u32x4& hi) {
-        const u32x4 oa = pair(set_c, i, 0, 1), ob = pair(set_c, i, 2, 3);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            lo[d] = (unsigned)__builtin_amdgcn_update_dpp((int)oa[d], (int)ob[d], 0x118 /* row_shr:8 */, 0xF, 0xC, false);
-            hi[d] = (unsigned)__builtin_amdgcn_update_dpp((int)ob[d], (int)oa[d], 0x108 /* row_shl:8 */, 0xF, 0x3, false);
-        }
-    };
-    auto tile_out = [&](int t) {  // this wave's quadrant of tile t in C
-        int tm, tn;
-        tile_from_t(t, tiles_m, tiles_n, tm, tn);
-        return C + ((int64_t)tm * BM + wm * NT4_WM) * ldc + (int64_t)tn * PP_BN + wn * PP_WN;
-    };
-    const int voff = (int)((lane_row * ldc + lane_col) * 2);
-    auto epilogue = [&](auto set_c, int t) {
-        const __amdgpu_buffer_rsrc_t rsC = make_rsrc(tile_out(t));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            u32x4 lo, hi;
-            duo(set_c, i, lo, hi);
-            __builtin_amdgcn_raw_buffer_store_b128(lo, rsC, voff, (int)((i * 16) * ldc * 2), NT4_ST_AUX);
-            __builtin_amdgcn_raw_buffer_store_b128(hi, rsC, voff, (int)((i * 16 + 8) * ldc * 2), NT4_ST_AUX);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    if constexpr (!PINGPONG) {
-        while (cur >= 0) {
-            zero_acc(B0_{});
-            for (int kt = 0; kt < nk; ++kt) kstep(B0_{}, nohook, nohook);
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the asm MFMAs are opaque to the hazard recogniser: let the last results land
-            epilogue(B0_{}, cur);
-            cur = nxt;
-            if (cur >= 0) nxt = receive_tile();
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this workgroup in flight towards LDS when it ends
-}
-
-int launch_nt4pp(bool pingpong, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                 float alpha, hipStream_t st) {
-    auto kern = pingpong ? gemm_nt4pp_kernel<true> : gemm_nt4pp_kernel<false>;
-    static const hipError_t rc0 = hipFuncSetAttribute((const void*)gemm_nt4pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-    static const hipError_t rc1 = hipFuncSetAttribute((const void*)gemm_nt4pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-    if (rc0 != hipSuccess || rc1 != hipSuccess) return SSI_ERR_HIP;
-    const int tm = (int)(M / BM), tn = (int)(N / PP_BN), ntiles = tm * tn;
-    const int grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), PP_LDS_BYTES, st, tm, tn, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc,
-                       alpha);
-    SSI_LAUNCH_CHECK();
-    return SSI_OK;
-}
-
 // Main loop of the persistent kernel per operand form: 1 = LDS-DMA (default: +7..15 % on every form of the step, profiles/r02_*), 0 = the
 // register-staged loop (kept for A/B builds: -DSSI_NT_DMA=0 -DSSI_NN_DMA=0 -DSSI_TN_DMA=0)
 #ifndef SSI_NT_DMA
@@ -1579,9 +1311,6 @@ int ssi_gemm_mfma_bf16(int layout, int64_t M, int64_t N, int64_t K, const void* 
             if (nt4_ok(K) && nt4_ld_ok(lda, ldb) && !(accumulate && R)) {
                 if (accumulate) return launch_nt4<false, false, EPI_PLAIN, 1, false, NT_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
                 if (R) return launch_nt4<false, false, EPI_PLAIN, 2, false, NT_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
-                if (const char* pp = getenv("SSI_GEMM_PP"))  // PROTOTYPE (read per call): 256 x 128 tiles; 1 = epilogue behind the K-loop, 2 = two accumulator sets
-                    if ((pp[0] == '1' || pp[0] == '2') && !alpha_dev && N % PP_BN == 0 && (M / BM) * (N / PP_BN) >= 256)
-                        return launch_nt4pp(pp[0] == '2', M, N, K, A, lda, B, ldb, C, ldc, alpha, st);
                 return launch_nt4<false, false, EPI_PLAIN, 0, false, NT_DMA>(tm, tn, K, A, lda, B, ldb, C, ldc, R, alpha, alpha_dev, st);
             }
             GO(false, false);
