@@ -12,9 +12,12 @@
  *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered.  Compute entries keep no per-call host state and may
  *     be called from any host thread (autograd runs backward on another thread than forward); their one-time set-up (LDS size
  *     attribute, CU count) is done under C++ thread-safe static initialisation.
- *   - PROCESS-GLOBAL state, stated here because it is not per call: (1) ssi_set_impl and (2) ssi_set_gemm_tile_order are switches
- *     for the whole process (atomics; meant to be set once at start-up — tests, A/B runs, the data-parallel trainer — not flipped
- *     while another thread is launching); (3) with SSI_TILES_DYNAMIC the persistent GEMM draws tiles from 16 scheduler slots in
+ *   - PROCESS-GLOBAL state, stated here because it is not per call: (1) ssi_set_impl, (2) ssi_set_gemm_tile_order and (4) ssi_set_attn_impl
+ *     are switches for the whole process (atomics; meant to be set once at start-up — tests, A/B runs, the data-parallel trainer — not
+ *     flipped while another thread is launching; (4) takes its initial values from the environment variables SSI_ATTN_DQ / SSI_ATTN_DKV,
+ *     read ONCE at first use, never on the launch path; the kernel choice moves results at the 1e-4 level — another summation order);
+ *     (5) ssi_attn_last_dispatch reports the choice of the most recent attention backward of the process (diagnostic);
+ *     (3) with SSI_TILES_DYNAMIC the persistent GEMM draws tiles from 16 scheduler slots in
  *     device memory handed out round-robin per launch, shared by all streams of the process: more than 16 persistent GEMMs in
  *     flight at once on one device would share a slot (the trainer has at most two).
  *   - return 0 on success; SSI_ERR_* otherwise (never throws).  ssi_last_error() gives a thread-local message.
@@ -31,7 +34,9 @@
 extern "C" {
 #endif
 
-#define SSI_ABI_VERSION 6 /* 6: + ssi_attn_bwd_workspace_bytes, ssi_attn_varlen_bwd_ws (attention backward with a caller-owned workspace)
+#define SSI_ABI_VERSION 7 /* 7: + ssi_set_attn_impl, ssi_attn_last_dispatch (no getenv on the launch path), ssi_attn_plan_* and ssi_attn_varlen_bwd_plan
+                           *    (packed rows on the pipelined backward kernels, host-built work plan)
+                           * 6: + ssi_attn_bwd_workspace_bytes, ssi_attn_varlen_bwd_ws (attention backward with a caller-owned workspace)
                            * 5: ssi_doc_ranges takes n_clamped (out-of-table positions are counted, not only clamped)
                            * 4: + ssi_gemm_batched
                            * 2: + ssi_attn_varlen_fwd/bwd(_rope), ssi_set_gemm_tile_order, NN form of ssi_gemm_swiglu_bwd
@@ -140,6 +145,47 @@ int ssi_attn_varlen_bwd_ws(const void* qkv, int64_t ld, const void* out, const v
                            float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope_table,
                            int64_t table_len, const int32_t* positions, int64_t batch, int64_t seq, int n_heads, int n_kv,
                            int head_dim, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Which kernels the attention backward may take (process-global, see "PROCESS-GLOBAL state" above).  `which`: SSI_ATTN_KERNEL_DQ or
+ * SSI_ATTN_KERNEL_DKV.  `mode`: AUTO = the dispatcher's choice by shape; OLD = the round-1..3 kernels (attn_bwd_dq_kernel / the 128-key
+ * attn_bwd_dkv_kernel); NEW = the pipelined one-wave-per-SIMD kernels wherever their shape rules allow, whatever the fill / balance;
+ * NO_HEAD_SPLIT (dK / dV only) = AUTO without the per-query-head split of small launches.  Returns the previous mode (an invalid `mode`
+ * only reads it; an invalid `which` returns -1).  Initial values: environment SSI_ATTN_DQ / SSI_ATTN_DKV = 0..3, read once. */
+enum { SSI_ATTN_KERNEL_DQ = 0, SSI_ATTN_KERNEL_DKV = 1 };
+enum { SSI_ATTN_MODE_AUTO = 0, SSI_ATTN_MODE_OLD = 1, SSI_ATTN_MODE_NEW = 2, SSI_ATTN_MODE_NO_HEAD_SPLIT = 3 };
+int ssi_set_attn_impl(int which, int mode);
+/* Kernels the most recent MFMA attention backward of this process launched (diagnostic; tests assert the dispatch with it, the secondary
+ * bench lines name the path a number came from): bit 0 dQ pipelined (attn_bwd_dq2_kernel), bit 1 dK/dV pipelined (attn_bwd_dkv2_kernel),
+ * bit 2 dK/dV split over the query heads, bit 3 the document-aware (plan) forms of the pipelined kernels; bits 8-11 query blocks per
+ * persistent dQ workgroup.  0 before any call and after a call that took the generic kernels. */
+enum { SSI_ATTN_USED_DQ2 = 1, SSI_ATTN_USED_DKV2 = 2, SSI_ATTN_USED_HEAD_SPLIT = 4, SSI_ATTN_USED_PLAN = 8 };
+int ssi_attn_last_dispatch(void);
+
+/* Work plan for packed rows on the pipelined backward kernels (the Trainer's default path: ssi/data/unpad.py turns every right-padded batch of
+ * the reference's collate function, ssi/data/__init__.py:139-199, into one packed row; plans/Feature - Packed Dataset Support.md:1-96).  The
+ * document bounds are known on the HOST wherever batches are collated, so the plan is built there (no device sync, in the prefetch thread)
+ * and travels to the device with the batch: every document is cut into dK/dV items (up to 256 keys of ONE document) and dQ items (a
+ * 64-query block of ONE document), sorted by work, the dQ items dealt to persistent workgroups of equal load.  Tiles outside an item's
+ * document are not in its tile list at all (skipped, not masked); the heaviest items start first whatever their place in the row.
+ *   host_doc_row / _start / _end: n_docs documents as (row b, first position, one past the last position) — they must tile every row.
+ *   flags: SSI_ATTN_PLAN_FORCE = build the plan even where the round-1..3 kernels are expected to be faster (tests).
+ *   ssi_attn_plan_words: upper bound of a plan's size in int32 words.  ssi_attn_plan_build: words written (> 0); 0 = the pipelined kernels
+ *   do not take this batch (other than 4 query heads per kv head, a document longer than 16 384 tokens, mostly tiny documents, a few long
+ *   documents and nothing else) — pass no plan then; < 0 = bad arguments.  The first SSI_ATTN_PLAN_HEADER words are the header the launch
+ *   reads on the host.  RoPE positions are taken to be (position - document start): build no plan for batches whose input_pos does
+ *   anything else. */
+enum { SSI_ATTN_PLAN_HEADER = 16, SSI_ATTN_PLAN_FORCE = 1 };
+int64_t ssi_attn_plan_words(int64_t batch, int64_t seq, int64_t n_docs);
+int64_t ssi_attn_plan_build(const int32_t* host_doc_row, const int32_t* host_doc_start, const int32_t* host_doc_end, int64_t n_docs,
+                            int64_t batch, int64_t seq, int n_heads, int n_kv, int flags, int32_t* host_plan, int64_t plan_words);
+/* ssi_attn_varlen_bwd_ws + a plan: plan = the plan in DEVICE memory, host_plan_header = its first SSI_ATTN_PLAN_HEADER words on the host
+ * (both NULL = ssi_attn_varlen_bwd_ws).  doc_start / doc_end stay required (kernels a mode switch sends back to the round-1..3 forms read
+ * them).  Results equal the plan-less call's to the rounding of another summation order; reproducible for a given plan. */
+int ssi_attn_varlen_bwd_plan(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
+                             float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope_table,
+                             int64_t table_len, const int32_t* positions, int64_t batch, int64_t seq, int n_heads, int n_kv,
+                             int head_dim, int dtype, void* workspace, int64_t workspace_bytes, const int32_t* plan,
+                             const int32_t* host_plan_header, void* stream);
 
 /* ---- K7  SwiGLU elementwise (torchtune FeedForward: w2(silu(w1 x) * w3 x)) ------------------------------------------ */
 /* gu: [rows, 2*inter] = [gate | up]; act[rows, inter] = silu(gate) * up */

@@ -13,8 +13,10 @@ bool ssi_attn_mfma_supported(int64_t ld, int64_t batch, int64_t seq, int n_heads
 int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, const int32_t* doc_start, int64_t batch, int64_t seq,
                       int n_heads, int n_kv, void* stream);
 int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
-                      float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope, const int32_t* positions,
-                      int64_t batch, int64_t seq, int n_heads, int n_kv, void* workspace, int64_t workspace_bytes, void* stream);
+                      float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope, int64_t table_len,
+                      const int32_t* positions, int64_t batch, int64_t seq, int n_heads, int n_kv, void* workspace, int64_t workspace_bytes,
+                      const int32_t* plan_dev, const int32_t* host_plan_header, void* stream);
+void ssi_attn_note_dispatch(int v);
 int64_t ssi_attn_mfma_bwd_workspace_bytes(int64_t batch, int64_t seq, int n_heads, int n_kv);
 extern "C" int ssi_rope_inplace(void* x, int64_t ld, int64_t rows, int64_t seq_len, int n_heads_rot, int head_dim, const float* table,
                                 int64_t table_len, const int32_t* positions, int inverse, int dtype, void* stream);
@@ -238,15 +240,17 @@ extern "C" int ssi_attn_varlen_fwd(const void* qkv, int64_t ld, void* out, float
 static int attn_varlen_bwd_impl(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
                                 float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope_table,
                                 int64_t table_len, const int32_t* positions, int64_t batch, int64_t seq, int n_heads, int n_kv,
-                                int head_dim, int dtype, void* stream, void* workspace = nullptr, int64_t workspace_bytes = 0) {
+                                int head_dim, int dtype, void* stream, void* workspace = nullptr, int64_t workspace_bytes = 0,
+                                const int32_t* plan = nullptr, const int32_t* host_plan_header = nullptr) {
     if (int rc = attn_check(qkv, ld, batch, seq, n_heads, n_kv, head_dim)) return rc;
     SSI_CHECK_ARG(out && dout && lse && dqkv && delta && ((doc_start == nullptr) == (doc_end == nullptr)));
     if (batch * seq == 0) return SSI_OK;
     const bool fast = ssi_attn_mfma_supported(ld, batch, seq, n_heads, n_kv, head_dim, dtype);
     if ((ssi_get_impl() == SSI_IMPL_MFMA || ssi_get_impl() == SSI_IMPL_MFMA_WG8) && !fast) { ssi_set_error("ssi_attn_bwd: MFMA path forced but unsupported shape"); return SSI_ERR_UNSUPPORTED; }
     if (fast && ssi_get_impl() != SSI_IMPL_GENERIC)
-        return ssi_attn_bwd_mfma(qkv, ld, out, dout, lse, dqkv, delta, doc_start, doc_end, rope_table, positions, batch, seq, n_heads, n_kv,
-                                 workspace, workspace_bytes, stream);
+        return ssi_attn_bwd_mfma(qkv, ld, out, dout, lse, dqkv, delta, doc_start, doc_end, rope_table, table_len, positions, batch, seq, n_heads,
+                                 n_kv, workspace, workspace_bytes, plan, host_plan_header, stream);
+    ssi_attn_note_dispatch(0);
     auto st = (hipStream_t)stream;
     const int64_t nq = batch * n_heads * seq, nk = batch * n_kv * seq;
     SSI_DISPATCH_DTYPE(dtype, ATTN_HD_SWITCH(head_dim, {
@@ -299,6 +303,19 @@ extern "C" int ssi_attn_varlen_bwd_ws(const void* qkv, int64_t ld, const void* o
     SSI_CHECK_ARG(workspace_bytes >= 0 && (workspace != nullptr || workspace_bytes == 0));
     return attn_varlen_bwd_impl(qkv, ld, out, dout, lse, dqkv, delta, doc_start, doc_end, rope_table, table_len, positions, batch, seq,
                                 n_heads, n_kv, head_dim, dtype, stream, workspace, workspace_bytes);
+}
+
+extern "C" int ssi_attn_varlen_bwd_plan(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
+                                        float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope_table,
+                                        int64_t table_len, const int32_t* positions, int64_t batch, int64_t seq, int n_heads, int n_kv,
+                                        int head_dim, int dtype, void* workspace, int64_t workspace_bytes, const int32_t* plan,
+                                        const int32_t* host_plan_header, void* stream) {
+    SSI_CHECK_ARG(!rope_table || positions != nullptr || table_len >= seq);
+    SSI_CHECK_ARG(workspace_bytes >= 0 && (workspace != nullptr || workspace_bytes == 0));
+    SSI_CHECK_ARG((plan == nullptr) == (host_plan_header == nullptr));
+    SSI_CHECK_ARG(!plan || (doc_start && doc_end && ((uintptr_t)plan & 15) == 0));
+    return attn_varlen_bwd_impl(qkv, ld, out, dout, lse, dqkv, delta, doc_start, doc_end, rope_table, table_len, positions, batch, seq,
+                                n_heads, n_kv, head_dim, dtype, stream, workspace, workspace_bytes, plan, host_plan_header);
 }
 
 extern "C" int ssi_attn_fwd(const void* qkv, int64_t ld, void* out, float* lse, int64_t batch, int64_t seq, int n_heads,

@@ -15,6 +15,9 @@
 // group).  No atomics anywhere: dQ gets its own pass (recomputing S and dP) so every output has exactly one writer and
 // results are bitwise reproducible.
 #include <stdlib.h>
+#include <algorithm>
+#include <atomic>
+#include <vector>
 #include <type_traits>
 #include "common_hip.h"
 
@@ -407,6 +410,7 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_fwd_kernel(co
         if (t + 2 < nt) tile_step(t + 2, std::integral_constant<int, 2>{});
     }
     TRACE_LOOP_END();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last tile's wait left nothing in flight towards LDS; once more on every path: kernel_lint R3)
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.f / ltot;
     bf16_t* orow = out + (row0 + qg) * ((int64_t)H * HD) + (int64_t)head * HD;
@@ -583,6 +587,7 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_bwd_dq_kernel
         if (t + 2 < nt) tile_step(t + 2, std::integral_constant<int, 2>{});
     }
     TRACE_LOOP_END();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see attn_fwd_kernel)
     bf16_t* drow = dqkv + (row0 + qg) * ld + (int64_t)head * HD;
 #ifdef DQ_STAMP
     unsigned long long qs_total = __builtin_readcyclecounter() - qs_begin;
@@ -683,17 +688,32 @@ constexpr Dq2Plan dq2_make_plan() {
 }
 constexpr Dq2Plan DQ2_PLAN = dq2_make_plan();
 
-template <int DQ2_ITEMS>  // query blocks per workgroup: 8, 4 or 2 (the host takes the largest that fills the chip in whole rounds)
+// VARLEN (round 5; DQ2_ITEMS = 0): packed rows.  The items come from a host-built PLAN (ssi_attn_plan_build): an item = (row b, 64-query block
+// q0 — a multiple of 64 —, document [dstart, dend)); a block that straddles a document boundary is two items.  A workgroup walks the items of
+// one GROUP of the plan (groups of equal total work: longest-processing-time assignment on the host, an item's work = its key tiles + its
+// fixed cost), heaviest first, for one kv head.  An item sweeps the key tiles dstart / 64 .. q0 / 64 of ITS document (tiles of other
+// documents are skipped); masked are its diagonal tile and, when the document does not start on a 64-row boundary, its first tile (keys
+// < dstart) — both by the one mask  dstart <= key <= query  in a masked loop of its own in front of / behind the plain loop.  Lanes whose query
+// lies outside [dstart, dend) compute on whatever their row holds and store nothing (query = lane: their columns stay their own).  RoPE
+// positions are query - dstart (the plan builder checks that input_pos runs 0, 1, 2, ... inside every document).
+template <int DQ2_ITEMS, bool VARLEN = false>  // query blocks per workgroup: 8, 4 or 2 (the host takes the largest that fills the chip in whole rounds)
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ out,
                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                               float* __restrict__ delta, bf16_t* __restrict__ dqkv,
-                                                              const float* __restrict__ rope, int S, int H, int KV, int W) {
+                                                              const float* __restrict__ rope, int S, int H, int KV, int W,
+                                                              const int4* __restrict__ groups, int group_stride, int table_len) {
     __shared__ __attribute__((aligned(16))) char smem[DQ2_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     // workgroup -> ((batch, kv head) pair, group g of its query blocks); an XCD gets whole pairs (their K / V stay in one L2)
     int pair, g;
-    {
+    const int4* gp = nullptr;  // VARLEN: this workgroup's group of the plan: [0].x = its item count, [1 ..] = the items
+    if constexpr (VARLEN) {
+        const int id = (int)blockIdx.x;
+        pair = id % KV;  // consecutive workgroups = the kv heads of one group, i.e. (KV = 8) kv head = XCD
+        g = id / KV;
+        gp = groups + (int64_t)g * group_stride;
+    } else {
         const int n_pairs = (int)gridDim.x / W, id = (int)blockIdx.x;
         if (n_pairs % 8 == 0) {
             const int ppx = n_pairs / 8, k = id >> 3;
@@ -704,7 +724,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
             g = id % W;
         }
     }
-    const int kvh = pair % KV, b = pair / KV;
+    const int n_items = VARLEN ? gp[0].x : DQ2_ITEMS;
+    const int kvh = pair % KV, b = VARLEN ? 0 : pair / KV;   // VARLEN: the row is the item's
     const int head = kvh * 4 + wave;
     const int64_t row0 = (int64_t)b * S, ldo = (int64_t)H * HD;
     const bf16_t* kbase = qkv + row0 * ld + (int64_t)H * HD + (int64_t)kvh * HD;
@@ -712,6 +733,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
     auto item_block = [&](int i) __attribute__((always_inline)) {
         const int u = (DQ2_ITEMS / 2 - 1) - (i >> 1);
         return u * 2 * W + ((i & 1) ? g : 2 * W - 1 - g);
+    };
+    // item i as (row offset of its batch row, query block, first key tile, document)
+    struct Item { int64_t r0; int jq, t0, ds, de; };
+    auto item_at = [&](int i) __attribute__((always_inline)) {
+        Item it;
+        if constexpr (VARLEN) {
+            const int4 v = gp[1 + i];  // (uniform address: a scalar load)
+            it.r0 = (int64_t)v.x * S, it.jq = v.y >> 6, it.t0 = v.z >> 6, it.ds = v.z, it.de = v.w;
+        } else {
+            it.r0 = row0, it.jq = item_block(i), it.t0 = 0, it.ds = 0, it.de = S;
+        }
+        return it;
     };
 
     KvTileDma<SWZ_DUAL, SWZ_ROW> kvdma;
@@ -727,8 +760,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
     const char* stage = smem + DQ2_STAGE + wave * (3 * 8192);
     const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)stage);
     // Q, dO and O rows of item block jq of this wave's head: 24 requests
-    auto request_stage = [&](int jq) __attribute__((always_inline)) {
-        const int64_t r = row0 + jq * 64;
+    auto request_stage = [&](int64_t r0_, int jq) __attribute__((always_inline)) {
+        const int64_t r = r0_ + jq * 64;
         const u32x4 rq = buffer_rsrc(qkv + r * ld + (int64_t)head * HD), rd = buffer_rsrc(dout + r * ldo + (int64_t)head * HD),
                     ro = buffer_rsrc(out + r * ldo + (int64_t)head * HD);
 #pragma unroll
@@ -743,7 +776,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
     const unsigned rope_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)(smem + DQ2_ROPE));
     const unsigned vrope = (unsigned)((lane >> 4) * 256 + (((lane & 15) ^ ((4 * wave + (lane >> 4)) & 15)) * 16));
     const u32x4 rope_rs = buffer_rsrc(rope ? (const void*)rope : (const void*)qkv);
-    auto lse_of = [&](int jq, int qb) __attribute__((always_inline)) { return lse[((int64_t)b * H + head) * S + jq * 64 + 32 * qb + (lane & 31)]; };
+    auto lse_of = [&](int64_t r0_, int jq, int qb) __attribute__((always_inline)) {  // lse is [B][H][S]: r0_ = b S
+        return lse[(r0_ * H + (int64_t)head * S) + jq * 64 + 32 * qb + (lane & 31)];
+    };
 
     // ---- per-tile register state ------------------------------------------------------------------------------------------------------------
     bf16x8 qf[2][4], dof[2][4];    // B operands: lane = query q0 + 32 qb + (l & 31), d = 16 ks + 8 h + j
@@ -794,9 +829,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
     bool beyond[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) beyond[r] = rowmap(r, h) > (lane & 31);
+    int ds_item = 0;  // VARLEN: first key of the item's document
     auto sm_gap = [&](auto edge_c, int par, int kb, int qb, int k0, int gap) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edge_c)::value;
-        if (EDGE && kb == 1 && qb == 0) {  // nothing visible: dS^T = 0
+        if (!VARLEN && EDGE && kb == 1 && qb == 0) {  // nothing visible: dS^T = 0
             if (gap == 0) dsu[par][0] = dsu[par][1] = u32x4{0u, 0u, 0u, 0u};
             return;
         }
@@ -810,7 +846,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
             } else if (kind == 1 || kind == 2) {
                 const int r = 2 * j + kind - 1;
                 float p = __builtin_amdgcn_exp2f(ev[j][kind - 1]);
-                if (EDGE && kb == qb && beyond[r]) p = 0.f;  // keys beyond the query contribute nothing
+                if constexpr (VARLEN) {  // a masked tile of a packed row (the document's first or the item's diagonal): dstart <= key <= query
+                    if (EDGE) {
+                        const int key = k0 + 32 * kb + rowmap(r, h);
+                        if (key > qg[qb] || key < ds_item) p = 0.f;
+                    }
+                } else if (EDGE && kb == qb && beyond[r]) p = 0.f;  // keys beyond the query contribute nothing
                 pv[r] = p;
             } else if (kind == 3) {
                 dsv[j][0] = pv[2 * j] * pacc[par][2 * j];  // dS^T (the 1/sqrt(d) factor is applied once at the end)
@@ -873,23 +914,31 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
     // ---- before the first item: its rows, its lse -------------------------------------------------------------------------------------------
     // the first three key tiles of an item of nt tiles; behind the last tile the last tile is requested again (into a slot nobody reads), so
     // that the counted vmcnt waits hold without a tail case and a trip has no branch
-    auto request_first_tiles = [&](int nt) __attribute__((always_inline)) {
-        kvdma.tile(0, 0);
-        kvdma.tile(nt > 1 ? 1 : 0, 16384);
-        kvdma.tile(nt > 2 ? 2 : nt - 1, 32768);
+    auto request_first_tiles = [&](int t0, int nt) __attribute__((always_inline)) {  // tiles t0 .. nt - 1
+        kvdma.tile(t0, 0);
+        kvdma.tile(t0 + 1 < nt ? t0 + 1 : t0, 16384);
+        kvdma.tile(t0 + 2 < nt ? t0 + 2 : nt - 1, 32768);
+    };
+    // K / V rows of the item's batch row (VARLEN: items of one group may lie in different rows)
+    auto kv_rows = [&](int64_t r0_) __attribute__((always_inline)) {
+        if constexpr (VARLEN) kvdma.rs = buffer_rsrc(qkv + r0_ * ld + (int64_t)H * HD + (int64_t)kvh * HD);
     };
     float lqn[2];
     {
-        const int j0 = item_block(0);
-        request_first_tiles(j0 + 1);
-        request_stage(j0);
-        lqn[0] = lse_of(j0, 0);
-        lqn[1] = lse_of(j0, 1);
+        const Item i0 = item_at(0);
+        kv_rows(i0.r0);
+        request_first_tiles(i0.t0, i0.jq + 1);
+        request_stage(i0.r0, i0.jq);
+        lqn[0] = lse_of(i0.r0, i0.jq, 0);
+        lqn[1] = lse_of(i0.r0, i0.jq, 1);
     }
 
-    for (int it = 0; it < DQ2_ITEMS; ++it) {
-        const int jq = item_block(it), jn = item_block(it + 1 < DQ2_ITEMS ? it + 1 : it);
-        const int q0 = jq * 64, nt = jq + 1;  // key tiles 0 .. jq; the last one holds the diagonal
+    for (int it = 0; it < n_items; ++it) {
+        const Item icur = item_at(it), inxt = item_at(it + 1 < n_items ? it + 1 : it);
+        const int jq = icur.jq, jn = inxt.jq;
+        const int q0 = jq * 64, nt = jq + 1;  // key tiles t0 .. jq; the last one holds the diagonal
+        const int64_t rw0 = icur.r0;          // row offset of the item's batch row
+        if constexpr (VARLEN) ds_item = icur.ds;
         const float lq0 = lqn[0], lq1 = lqn[1];
         // everything this wave has asked for is there: the item's rows (asked for an item ago), its first three tiles (asked for in front of
         // the store of the item before), that store
@@ -907,16 +956,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
         // in registers: the images are free for the next item's rows (this wave's own images: no barrier)
         asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(oraw[1][3]), "v"(dof[1][3]), "v"(qf[1][3]) : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        lqn[0] = lse_of(jn, 0);
-        lqn[1] = lse_of(jn, 1);
+        lqn[0] = lse_of(inxt.r0, jn, 0);
+        lqn[1] = lse_of(inxt.r0, jn, 1);
         // 28 requests — the table rows of THIS item (nobody reads the old ones any more: barrier at the end of the item before) and the next
         // item's rows — dealt over the 8 steps of the delta sums: back to back, four waves' requests queue up in front of the CU's one
         // address unit (~150 cycles each where a request inside the tile loop costs 40)
-        const int64_t rn = row0 + jn * 64;
+        const int64_t rn = inxt.r0 + jn * 64;
         const u32x4 rq = buffer_rsrc(qkv + rn * ld + (int64_t)head * HD), rd = buffer_rsrc(dout + rn * ldo + (int64_t)head * HD),
                     ro = buffer_rsrc(out + rn * ldo + (int64_t)head * HD);
         auto request = [&](int i) __attribute__((always_inline)) {
             if (i < 4) {
+                if constexpr (VARLEN) {  // table row of query q = its position q - dstart, kept inside the table for the lanes outside the document
+                    const int pr = q0 - icur.ds + 4 * (wave + 4 * i) + (lane >> 4);
+                    const int prc = pr < 0 ? 0 : (pr < table_len ? pr : table_len - 1);
+                    dma16(rope_lds + (wave + 4 * i) * 1024, (rope ? (unsigned)prc * 256u : 0u) + (vrope & 255u), rope_rs, 0u);
+                } else
                 dma16(rope_lds + (wave + 4 * i) * 1024, vrope, rope_rs, (unsigned)((rope ? q0 * 256 : 0) + (wave + 4 * i) * 1024));
             } else {
                 const int j = (i - 4) / 3, which = (i - 4) % 3;
@@ -941,7 +995,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
             }
             dl += __shfl_xor(dl, 32, 64);
             // for the dK / dV kernel, which runs after this one (every (row, head) belongs to exactly one wave)
-            if (h == 0) delta[((int64_t)b * H + head) * S + qg[qb]] = dl;
+            if (h == 0) delta[(rw0 * H + (int64_t)head * S) + qg[qb]] = dl;  // (a straddled block's two items write the same values)
             nlq[qb] = -(qb ? lq1 : lq0) * LOG2E;
 #pragma unroll
             for (int r = 0; r < 16; ++r) pdl[qb][r] = -dl;
@@ -983,8 +1037,28 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
         STAMPQ(2)
-        // ---- the unmasked tiles: 0 .. nt - 2 ------------------------------------------------------------------------------------------------
-        int t = 0;
+        int t = icur.t0;
+        if constexpr (VARLEN) {
+            // ---- packed rows: the document's first tile when it holds keys of the document before (dstart off the 64-row grid) and is not
+            // the diagonal tile: the masked form of a full trip.  A loop of zero or one trip (see below why a loop)
+            const int t_head = ((icur.ds & 63) && t + 1 < nt) ? t + 1 : t;
+            for (; t < t_head; ++t) {
+                const int k0 = t * 64;
+                const int t3 = t + 3 < nt ? t + 3 : nt - 1;
+                MFMA_GUARD();
+                period(T_{}, F_{}, T_{}, U3, U0, U1, k0, [&](int m) __attribute__((always_inline)) { if (m < 8) read_rows(ring_cur, 1, m); }, none, [&]() __attribute__((always_inline)) { rows_landed(1); });
+                period(T_{}, F_{}, T_{}, U0, U1, U2, k0, [&](int m) __attribute__((always_inline)) { if (m < 8) read_tr(ring_cur, 1, m); }, none, [&]() __attribute__((always_inline)) { tr_landed(1); });
+                period(T_{}, T_{}, T_{}, U1, U2, U3, k0, [&](int m) __attribute__((always_inline)) { if (m < 8) read_rows(ring_nxt, 0, m); },
+                       [&](int m) __attribute__((always_inline)) { if (m >= 8) kvdma.piece(t3, ring_cur, m - 8); }, [&]() __attribute__((always_inline)) { rows_landed(0); });
+                period(T_{}, F_{}, T_{}, U2, U3, U0, k0, [&](int m) __attribute__((always_inline)) { if (m < 8) read_tr(ring_nxt, 0, m); }, none, [&]() __attribute__((always_inline)) { tr_landed(0); });
+                const unsigned c = ring_cur;
+                ring_cur = ring_nxt;
+                ring_nxt = ring_n2;
+                ring_n2 = c;
+            }
+            MFMA_DRAIN();
+        }
+        // ---- the unmasked tiles: t0 .. nt - 2 -----------------------------------------------------------------------------------------------
         for (; t + 1 < nt; ++t) {
             const int k0 = t * 64;
             const int t3 = t + 3 < nt ? t + 3 : nt - 1;  // (a select)
@@ -1033,11 +1107,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
         }
         // everybody has its table rows in registers and is done with the ring: the next item's requests may overwrite both
         ring_barrier();
-        request_first_tiles(jn + 1);  // (behind the last item: its own once more — waited for at the end of the kernel)
+        kv_rows(inxt.r0);
+        request_first_tiles(inxt.t0, jn + 1);  // (behind the last item: its own once more — waited for at the end of the kernel)
         STAMPQ(5)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            bf16_t* drow = dqkv + (row0 + qg[qb]) * ld + (int64_t)head * HD;
+            bf16_t* drow = dqkv + (rw0 + qg[qb]) * ld + (int64_t)head * HD;
+            const bool mine = !VARLEN || (qg[qb] >= icur.ds && qg[qb] < icur.de);  // packed rows: queries of other documents are other items'
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -1047,15 +1123,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq2_kernel(const bf16_t* __re
                     for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(dq[qb][db][4 * gg + e] * 0.125f);
                     // rope != NULL: the gradient leaves in pre-RoPE space (backward of the rotation fused here, saves a pass over dqkv)
                     if (rope) v = unrope4(v, rcs[qb][db][gg]);
-                    *reinterpret_cast<bf16x4*>(drow + db * 32 + 8 * gg + 4 * h) = v;
+                    if (mine) *reinterpret_cast<bf16x4*>(drow + db * 32 + 8 * gg + 4 * h) = v;
                 }
         }
         STAMPQ(6)
 #ifdef DQ2_STAMP
-        if (it == DQ2_ITEMS - 1 && wave == 0) {  // DEBUG BUILD ONLY: overwrites the first floats of the item's first dq row
+        if (it == n_items - 1 && wave == 0) {  // DEBUG BUILD ONLY: overwrites the first floats of the item's first dq row
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) {
-                float* dbg = reinterpret_cast<float*>(dqkv + (row0 + q0) * ld + (int64_t)head * HD);
+                float* dbg = reinterpret_cast<float*>(dqkv + (rw0 + q0) * ld + (int64_t)head * HD);
                 for (int i = 0; i < 7; ++i) dbg[i] = (float)stq_acc[i];
                 dbg[7] = (float)(__builtin_readcyclecounter() - stq_begin);
                 dbg[8] = (float)(__builtin_amdgcn_s_memrealtime() - stq_rt0);
@@ -1298,6 +1374,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(const bf16
         }
     }
     TRACE_LOOP_END();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see attn_fwd_kernel)
 #ifdef DKV_STAMP
     if (lane == 0 && wave == 0) {  // DEBUG BUILD ONLY: overwrites the first floats of the workgroup's first dq row
         float* dbg = reinterpret_cast<float*>(dqkv + (row0 + kgrp * 128) * ld);
@@ -1370,23 +1447,42 @@ constexpr int DKV2_RING = 12;
 constexpr int DKV2_SB = 8192 + 256;
 constexpr int DKV2_MAX_STEPS = 2048;  // tiles per workgroup = (S / 32) * rep at most: S <= 16384 at rep = 4
 
+// VARLEN (round 5): packed rows.  The work comes from a host-built PLAN (ssi_attn_plan_build): an item = (row b, first key k0 — a multiple of
+// 32 —, document [dstart, dend)) = the up to 256 keys k0 .. k0 + 255 of ONE document, items sorted by work, heaviest first; a workgroup =
+// (item, kv head).  Because an item never leaves its document, everything that made packed rows expensive in the 128-key kernel is uniform
+// here: the query tiles are those from k0 to the END OF THE DOCUMENT (tiles of other documents are skipped, not masked — they are simply
+// not in the tile table), the masked tiles are the 8 on the diagonal plus the document's last tile when the document does not end on a
+// 32-row boundary (queries >= dend belong to the next document), and the mask is  key <= query < dend  with dend a scalar.  Lanes whose key
+// lies outside [dstart, dend) — the head of the first item of a document that does not start on a 32-row boundary, the tail of its last
+// item — compute on clamped rows and store nothing (key = lane: whatever they accumulate stays in their own columns).
+template <bool VARLEN>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, const float* __restrict__ rope,
-                                                               const int32_t* __restrict__ positions, int S, int H, int KV) {
+                                                               const int32_t* __restrict__ positions, int S, int H, int KV,
+                                                               const int4* __restrict__ items) {
     constexpr int SB = DKV2_SB, RING = DKV2_RING;
     __shared__ __attribute__((aligned(16))) char smem[RING * SB + DKV2_MAX_STEPS * 4];  // ring of [Q tile 4 KiB | dO tile 4 KiB | lse 128 B | delta 128 B], tile table
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rep = H / KV;
-    const int ngrp = S / 256;
-    int kgrp, pair_;  // low key groups (most work) are dispatched first
-    block_to_work(ngrp, (int)(gridDim.x / ngrp), kgrp, pair_);
-    const int kvh = pair_ % KV;
-    const int b = pair_ / KV;
+    int kvh, b, k0, dstart = 0, dend = S;
+    if constexpr (VARLEN) {  // workgroup -> (item, kv head): consecutive workgroups = the kv heads of one item, i.e. (KV = 8) one per XCD
+        const int id = (int)blockIdx.x;
+        kvh = id % KV;
+        const int4 it = items[id / KV];  // (uniform address: scalar loads)
+        b = it.x, k0 = it.y, dstart = it.z, dend = it.w;
+    } else {
+        const int ngrp = S / 256;
+        int kgrp, pair_;  // low key groups (most work) are dispatched first
+        block_to_work(ngrp, (int)(gridDim.x / ngrp), kgrp, pair_);
+        kvh = pair_ % KV;
+        b = pair_ / KV;
+        k0 = kgrp * 256;
+    }
     const int h = lane >> 5;
     const int64_t row0 = (int64_t)b * S;
     const int64_t ldo = (int64_t)H * HD;
-    const int key0 = kgrp * 256 + wave * 64;
+    const int key0 = k0 + wave * 64;
 
     // operands and row constants exactly as in attn_bwd_dkv_kernel: -K * 2^-3 and -V as B operands, +lse / +delta as initial accumulators
     bf16x8 kf[2][4], vf[2][4];
@@ -1394,7 +1490,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         kg[kb] = key0 + 32 * kb + (lane & 31);
-        const bf16_t* krow = qkv + (row0 + kg[kb]) * ld + (int64_t)H * HD + (int64_t)kvh * HD + 8 * h;
+        const int krow_i = VARLEN ? (kg[kb] < S ? kg[kb] : S - 1) : kg[kb];  // (an item's last keys may lie beyond the row: not stored)
+        const bf16_t* krow = qkv + (row0 + krow_i) * ld + (int64_t)H * HD + (int64_t)kvh * HD + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             kf[kb][ks] = scale_frag(*reinterpret_cast<const bf16x8*>(krow + 16 * ks), -0.125f);
@@ -1413,8 +1510,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dk[kb][i][r] = 0.f; dv[kb][i][r] = 0.f; }
 
-    const int qb_first = kgrp * 8;                                       // first 32-query tile that sees any key of the group
-    const int per_head = S / 32 - qb_first;                              // tiles per query head (>= 8)
+    const int qb_first = k0 / 32;                                        // first 32-query tile that sees any key of the group
+    const int per_head = (VARLEN ? (dend + 31) / 32 : S / 32) - qb_first;  // tiles per query head (plain rows: >= 8)
     const int n_steps = per_head * rep;                                  // a multiple of 4: the host takes this kernel for rep % 4 == 0 only
 
     // ---- LDS-DMA requests: as in attn_bwd_dkv_kernel, three per tile and wave, issued part by part ----------------------------------------
@@ -1423,7 +1520,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
     // arch VGPRs and copies them into the accumulation registers in front of every MFMA (1 500 v_accvgpr moves and 400 scratch accesses in
     // the loop of the first build).  The order of the sums over the tiles differs from attn_bwd_dkv_kernel's, so the two kernels agree to
     // rounding, not bit for bit; each is reproducible run to run.
-    constexpr int n_edge = 8;                   // masked tiles per head: the group's diagonal
+    // masked tiles per head: the group's diagonal (8 tiles; fewer when the document ends inside it), and with VARLEN the document's last tile
+    // when it is not on the diagonal and holds queries of the next document
+    const int n_diag = VARLEN ? (per_head < 8 ? per_head : 8) : 8;
+    const int n_edge = VARLEN ? n_diag + ((per_head > 8 && (dend & 31)) ? 1 : 0) : 8;
     const int n_masked = n_edge * rep;          // tiles of the first loop; a multiple of 4, like n_steps
     // tile i of the sequence -> (head << 16) | tile of the head, looked up in a table in LDS behind the ring (built once per workgroup): the
     // requests run 6-7 tiles ahead of the products and cross heads and loops at other times, and a cursor kept in scalar registers by selects
@@ -1431,7 +1531,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
     int* seq_tab = reinterpret_cast<int*>(smem + RING * SB);
     for (int i = tid; i < n_steps; i += 256) {
         const int j = i < n_masked ? i : i - n_masked, len = i < n_masked ? n_edge : per_head - n_edge;
-        seq_tab[i] = ((j / len) << 16) | ((i < n_masked ? 0 : n_edge) + j % len);
+        int tile = (i < n_masked ? 0 : n_diag) + j % len;
+        if (VARLEN && i < n_masked && j % len >= n_diag) tile = per_head - 1;  // the document's last tile
+        seq_tab[i] = ((j / len) << 16) | tile;
     }
     const int irow = wave * 8 + (lane >> 3), ichunk = (lane & 7) ^ swz<SWZ_DUAL>(wave * 8 + (lane >> 3));
     const u32x4 rs_q = buffer_rsrc(qkv + row0 * ld + (int64_t)kvh * rep * HD);
@@ -1531,7 +1633,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
             float p = __builtin_amdgcn_exp2f(sacc[kb][g] * -LOG2E);
             if (EDGE) {
                 const int q = q0 + rowmap(g, h);
-                if (kg[kb] > q) p = 0.f;  // keys beyond the query contribute nothing
+                if (VARLEN ? (kg[kb] > q || q >= dend) : kg[kb] > q) p = 0.f;  // keys beyond the query (queries beyond the document) contribute nothing
             }
             pv[g] = p;
         }
@@ -1678,7 +1780,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
         int q0[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            q0[i] = (qb_first + cur_qt) * 32;
+            q0[i] = (qb_first + (VARLEN && cur_qt >= n_diag ? per_head - 1 : cur_qt)) * 32;
             cur_qt = cur_qt + 1 == n_edge ? 0 : cur_qt + 1;
         }
         using P0 = std::integral_constant<int, 0>;
@@ -1712,6 +1814,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
     const float* tb0 = rope ? rope : nullptr;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+        if (VARLEN && (kg[kb] < dstart || kg[kb] >= dend)) continue;  // another item's key (or none)
         bf16_t* krow_out = dqkv + (row0 + kg[kb]) * ld + (int64_t)H * HD + (int64_t)kvh * HD;
         bf16_t* vrow_out = krow_out + (int64_t)KV * HD;
         const float* tb = tb0 ? tb0 + (int64_t)(positions ? positions[row0 + kg[kb]] : kg[kb]) * HD : nullptr;  // dK leaves in pre-RoPE space
@@ -1732,16 +1835,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
     }
 #ifdef DKV2_STAMP
     if (wave == 0 && lane == 0) {  // DEBUG BUILD ONLY: overwrites the first floats of the workgroup's first dq row
-        float* dbg = reinterpret_cast<float*>(dqkv + (row0 + kgrp * 256) * ld);
+        float* dbg = reinterpret_cast<float*>(dqkv + (row0 + k0) * ld);
         for (int i = 0; i < 8; ++i) dbg[i] = (float)st2_acc[i];
         dbg[8] = (float)st2_total;
         dbg[9] = (float)n_steps;
-        dbg[10] = (float)kgrp;
+        dbg[10] = (float)(k0 / 256);
     }
 #endif
 #ifdef DKV2_STAMP_GAPS
     if (wave == 0 && lane == 0) {  // DEBUG BUILD ONLY
-        float* dbg = reinterpret_cast<float*>(dqkv + (row0 + kgrp * 256) * ld);
+        float* dbg = reinterpret_cast<float*>(dqkv + (row0 + k0) * ld);
         for (int i = 0; i < 32; ++i) dbg[i] = (float)sg_acc[i];
         dbg[32] = (float)n_steps;
     }
@@ -1787,6 +1890,24 @@ __global__ __launch_bounds__(256) void attn_dkv_head_reduce_kernel(const float* 
     *reinterpret_cast<bf16x4*>(dst) = o;
 }
 
+// Which backward kernels ssi_attn_bwd_mfma may take (ssi_set_attn_impl; process-global like ssi_set_impl).  The environment variables
+// SSI_ATTN_DQ / SSI_ATTN_DKV give the INITIAL values, read once under C++ static initialisation — never on the launch path.
+static int attn_env_mode(const char* name, int max_mode) {
+    const char* s = getenv(name);
+    const int v = (s && s[0] >= '0' && s[0] <= '9' && !s[1]) ? s[0] - '0' : 0;
+    return v <= max_mode ? v : 0;
+}
+static std::atomic<int>& attn_mode(int which) {
+    static std::atomic<int> modes[2] = {{attn_env_mode("SSI_ATTN_DQ", SSI_ATTN_MODE_NEW)}, {attn_env_mode("SSI_ATTN_DKV", SSI_ATTN_MODE_NO_HEAD_SPLIT)}};
+    return modes[which];
+}
+extern "C" int ssi_set_attn_impl(int which, int mode) {
+    if (which != SSI_ATTN_KERNEL_DQ && which != SSI_ATTN_KERNEL_DKV) return -1;
+    const int max_mode = which == SSI_ATTN_KERNEL_DQ ? SSI_ATTN_MODE_NEW : SSI_ATTN_MODE_NO_HEAD_SPLIT;
+    if (mode < 0 || mode > max_mode) return attn_mode(which).load(std::memory_order_relaxed);
+    return attn_mode(which).exchange(mode, std::memory_order_relaxed);
+}
+
 // fp32 workspace the head-split dK / dV form wants for this shape (0: the launch fills the chip without it, or a single head per kv head)
 // Workgroups per key group of the split form: all `rep` heads apart below 512 workgroups (two fit a CU: 512 fill the chip once, and the heaviest
 // of them — queries x heads steps — is as long as the launch), two halves below 1024 (one long packed row: B = 1, S = 11 520 gives 720 workgroups
@@ -1825,55 +1946,176 @@ int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, const 
     return SSI_OK;
 }
 
+// ---- work plan for packed rows (ABI v7) --------------------------------------------------------------------------------------------------
+// Layout of a plan (int32 words; built on the HOST by ssi_attn_plan_build, copied to the device by the caller; the first SSI_ATTN_PLAN_HEADER
+// words are also what the launch needs on the host):
+//   [0] magic  [1] n_dkv_items  [2] word offset of the dK/dV items  [3] n_dq_groups  [4] word offset of the dQ groups  [5] words per dQ group
+//   [6] batch  [7] seq  [8] n_heads  [9] n_kv  [10] total words  [11] n_docs  [12 ..15] reserved
+//   dK/dV items: n_dkv_items x {b, k0, dstart, dend}, heaviest first (see attn_bwd_dkv2_kernel<true>)
+//   dQ groups  : n_dq_groups x [{n_items, load, 0, 0}, cap x {b, q0, dstart, dend}] (see attn_bwd_dq2_kernel<0, true>)
+constexpr int32_t PLAN_MAGIC = 0x53534950;  // "SSIP"
+static_assert(SSI_ATTN_PLAN_HEADER == 16, "plan header");
+
+extern "C" int64_t ssi_attn_plan_words(int64_t batch, int64_t seq, int64_t n_docs) {
+    if (batch <= 0 || seq <= 0 || n_docs <= 0) return 0;
+    const int64_t dkv = batch * seq / 256 + 2 * n_docs, dq = batch * seq / 64 + 2 * n_docs;
+    return SSI_ATTN_PLAN_HEADER + 4 * dkv + 4 * (dq + 512 /* group headers */ + dq /* slack of the fixed group stride */);
+}
+
+// Returns the number of words written (> 0), 0 when the pipelined kernels do not take this batch (the caller then passes no plan and the
+// round-1..3 kernels run), < 0 on a bad argument.
+extern "C" int64_t ssi_attn_plan_build(const int32_t* host_doc_row, const int32_t* host_doc_start, const int32_t* host_doc_end, int64_t n_docs,
+                                       int64_t batch, int64_t seq, int n_heads, int n_kv, int flags, int32_t* host_plan, int64_t plan_words) {
+    if (!host_doc_row || !host_doc_start || !host_doc_end || !host_plan || n_docs <= 0 || batch <= 0 || seq <= 0 || n_heads <= 0 || n_kv <= 0) return -1;
+    if (plan_words < ssi_attn_plan_words(batch, seq, n_docs)) return -1;
+    const bool force = (flags & SSI_ATTN_PLAN_FORCE) != 0;
+    if (n_heads != 4 * n_kv || seq % 128 != 0 || seq > (1 << 24)) return 0;  // the pipelined kernels: 4 query heads per kv head
+    struct It { int32_t b, r0, ds, de, work; };
+    std::vector<It> dkv, dq;
+    std::vector<int64_t> covered((size_t)batch, 0);
+    int64_t keys = 0;
+    for (int64_t d = 0; d < n_docs; ++d) {
+        const int32_t b = host_doc_row[d], ds = host_doc_start[d], de = host_doc_end[d];
+        if (b < 0 || b >= batch || ds < 0 || de <= ds || de > seq) return -1;
+        covered[(size_t)b] += de - ds;
+        keys += de - ds;
+        for (int32_t k0 = ds & ~31; k0 < de; k0 += 256) {
+            const int per_head = (de + 31) / 32 - k0 / 32;
+            if (per_head * 4 > DKV2_MAX_STEPS) return 0;  // a document longer than the tile table
+            dkv.push_back({b, k0, ds, de, per_head});
+        }
+        for (int32_t q0 = ds & ~63; q0 < de; q0 += 64) dq.push_back({b, q0, ds, de, (q0 >> 6) - (ds >> 6) + 1});
+    }
+    for (int64_t b = 0; b < batch; ++b)
+        if (covered[(size_t)b] != seq) return -1;  // the documents must tile every row (overlaps are the caller's bug; gaps are caught here)
+    // stable sorts by work, heaviest first (ties keep document order: reproducible plans)
+    auto by_work = [](const It& x, const It& y) { return x.work > y.work; };
+    std::stable_sort(dkv.begin(), dkv.end(), by_work);
+    std::stable_sort(dq.begin(), dq.end(), by_work);
+    if (!force) {
+        // many short documents: an item has room for 256 keys (dK/dV) / 64 queries (dQ) whatever the document holds
+        if ((int64_t)dkv.size() * 256 > 2 * keys + 2048 || (int64_t)dq.size() * 64 > 2 * keys + 2048) return 0;
+        // dK/dV is one workgroup per (item, kv head) and CU: a launch lasts at least as long as its heaviest item.  Up to twice the chip's
+        // share per CU is accepted (the 128-key kernel this would fall back to suffers from the same long documents); beyond that — a few
+        // long documents and nothing else — its split over the query heads is the better tool
+        int64_t total = 0;
+        for (const It& it : dkv) total += it.work;
+        if ((int64_t)dkv[0].work * 256 > 2 * total * n_kv) return 0;
+    }
+    // dQ: groups of equal load for persistent workgroups, one round of the chip (256 workgroups over n_kv heads), longest processing time first
+    const int fixed_cost = 6;  // an item's cost outside its tiles, in tiles (14 000 of ~2 400 cycles)
+    int n_groups = (int)std::min<int64_t>((int64_t)dq.size(), std::max<int64_t>(1, 256 / n_kv));
+    std::vector<std::vector<It>> groups((size_t)n_groups);
+    std::vector<int64_t> load((size_t)n_groups, 0);
+    for (const It& it : dq) {
+        int g = 0;
+        for (int j = 1; j < n_groups; ++j)
+            if (load[(size_t)j] < load[(size_t)g]) g = j;
+        groups[(size_t)g].push_back(it);
+        load[(size_t)g] += it.work + fixed_cost;
+    }
+    size_t cap = 0;
+    for (const auto& g : groups) cap = std::max(cap, g.size());
+    const int64_t gstride = 4 * (1 + (int64_t)cap);
+    const int64_t dkv_off = SSI_ATTN_PLAN_HEADER, dq_off = dkv_off + 4 * (int64_t)dkv.size();
+    const int64_t words = dq_off + gstride * n_groups;
+    if (words > plan_words) return -1;
+    int32_t* hd = host_plan;
+    for (int i = 0; i < SSI_ATTN_PLAN_HEADER; ++i) hd[i] = 0;
+    hd[0] = PLAN_MAGIC, hd[1] = (int32_t)dkv.size(), hd[2] = (int32_t)dkv_off, hd[3] = n_groups, hd[4] = (int32_t)dq_off, hd[5] = (int32_t)gstride;
+    hd[6] = (int32_t)batch, hd[7] = (int32_t)seq, hd[8] = n_heads, hd[9] = n_kv, hd[10] = (int32_t)words, hd[11] = (int32_t)n_docs;
+    int32_t* w = host_plan + dkv_off;
+    for (const It& it : dkv) { w[0] = it.b, w[1] = it.r0, w[2] = it.ds, w[3] = it.de; w += 4; }
+    for (int g = 0; g < n_groups; ++g) {
+        w = host_plan + dq_off + gstride * g;
+        w[0] = (int32_t)groups[(size_t)g].size(), w[1] = (int32_t)load[(size_t)g], w[2] = w[3] = 0;
+        w += 4;
+        for (size_t i = 0; i < cap; ++i, w += 4) {
+            if (i < groups[(size_t)g].size()) { const It& it = groups[(size_t)g][i]; w[0] = it.b, w[1] = it.r0, w[2] = it.ds, w[3] = it.de; }
+            else w[0] = w[1] = w[2] = w[3] = 0;
+        }
+    }
+    return words;
+}
+
+static std::atomic<int> g_last_dispatch{0};
+void ssi_attn_note_dispatch(int v) { g_last_dispatch.store(v, std::memory_order_relaxed); }
+extern "C" int ssi_attn_last_dispatch(void) { return g_last_dispatch.load(std::memory_order_relaxed); }
+
+// plan_dev: the plan in device memory, host_plan_header: its first SSI_ATTN_PLAN_HEADER words on the host (both NULL: no plan)
 int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
-                      const int32_t* doc_start, const int32_t* doc_end, const float* rope, const int32_t* positions, int64_t batch,
-                      int64_t seq, int n_heads, int n_kv, void* workspace, int64_t workspace_bytes, void* stream) {
+                      const int32_t* doc_start, const int32_t* doc_end, const float* rope, int64_t table_len, const int32_t* positions,
+                      int64_t batch, int64_t seq, int n_heads, int n_kv, void* workspace, int64_t workspace_bytes, const int32_t* plan_dev,
+                      const int32_t* host_plan_header, void* stream) {
     auto st = (hipStream_t)stream;
     const int rep = n_heads / n_kv, qpw = ANW / rep;
+    int used = 0;
+    const int selq = attn_mode(SSI_ATTN_KERNEL_DQ).load(std::memory_order_relaxed);
+    const int sel = attn_mode(SSI_ATTN_KERNEL_DKV).load(std::memory_order_relaxed);
+    // packed rows with a plan: the document-aware forms of the pipelined kernels (mode OLD sends either kernel back to the round-1..3 one)
+    const int32_t* ph = (plan_dev && host_plan_header) ? host_plan_header : nullptr;
+    if (ph) {
+        if (ph[0] != PLAN_MAGIC || ph[6] != batch || ph[7] != seq || ph[8] != n_heads || ph[9] != n_kv || rep != 4 || !doc_start || !doc_end ||
+            ph[1] <= 0 || ph[3] <= 0 || (rope && table_len <= 0)) {
+            ssi_set_error("ssi_attn_varlen_bwd_plan: the plan does not belong to this batch (magic %x, batch %d, seq %d, heads %d / %d)", ph[0], ph[6],
+                          ph[7], ph[8], ph[9]);
+            return SSI_ERR_ARG;
+        }
+    }
     // dQ: the pipelined one-wave-per-SIMD kernel (persistent workgroups of 8, 4 or 2 query blocks: the largest count whose workgroups fill
-    // the chip in whole rounds of 256, or in many rounds) for plain causal rows of 4 query heads per kv head; SSI_ATTN_DQ=1 (read per call:
-    // in-run A/B) keeps the round-1..3 kernel, =2 forces this one (8 blocks per workgroup if S allows, else 4, 2) whatever the fill
-    const char* selq = getenv("SSI_ATTN_DQ");
+    // the chip in whole rounds of 256, or in many rounds) for plain causal rows of 4 query heads per kv head; ssi_set_attn_impl(DQ, OLD)
+    // keeps the round-1..3 kernel, NEW forces this one (8 blocks per workgroup if S allows, else 4, 2) whatever the fill
     int dq2_items = 0;
-    if (!doc_start && !positions && rep == 4 && seq % 128 == 0 && !(selq && selq[0] == '1')) {
+    if (!doc_start && !positions && rep == 4 && seq % 128 == 0 && selq != SSI_ATTN_MODE_OLD) {
         const int64_t nqb = seq / 64;
         for (int it = 8; it >= 2 && !dq2_items; it >>= 1) {
             if (nqb % it) continue;
             const int64_t grid = batch * n_kv * (nqb / it);
             if (grid % 256 == 0 || grid >= 1024) dq2_items = it;
         }
-        if (!dq2_items && selq && selq[0] == '2') dq2_items = nqb % 8 == 0 ? 8 : nqb % 4 == 0 ? 4 : 2;
+        if (!dq2_items && selq == SSI_ATTN_MODE_NEW) dq2_items = nqb % 8 == 0 ? 8 : nqb % 4 == 0 ? 4 : 2;
     }
-    if (dq2_items) {
+    if (ph && selq != SSI_ATTN_MODE_OLD) {
+        hipLaunchKernelGGL((attn_bwd_dq2_kernel<0, true>), dim3((unsigned)(ph[3] * n_kv)), dim3(256), 0, st, (const bf16_t*)qkv, ld, (const bf16_t*)out,
+                           (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, rope, (int)seq, n_heads, n_kv, 0,
+                           reinterpret_cast<const int4*>(plan_dev + ph[4]), ph[5] / 4, (int)std::min<int64_t>(table_len, 1 << 30));
+        used |= SSI_ATTN_USED_DQ2 | SSI_ATTN_USED_PLAN;
+    } else if (dq2_items) {
         const int w = (int)(seq / 64 / dq2_items);
         const dim3 grid((unsigned)(batch * n_kv * w));
         auto kern = dq2_items == 8 ? attn_bwd_dq2_kernel<8> : dq2_items == 4 ? attn_bwd_dq2_kernel<4> : attn_bwd_dq2_kernel<2>;
         hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, (const bf16_t*)qkv, ld, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv,
-                           rope, (int)seq, n_heads, n_kv, w);
+                           rope, (int)seq, n_heads, n_kv, w, (const int4*)nullptr, 0, 0);
+        used |= SSI_ATTN_USED_DQ2 | (dq2_items << 8);
     }
     else
         hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * n_kv * (seq / (32 * qpw)))), dim3(64 * ANW), 0, st, (const bf16_t*)qkv,
                            ld, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_start, rope, positions, (int)seq, n_heads, n_kv);
     SSI_LAUNCH_CHECK();
     // dK / dV: the pipelined one-wave-per-SIMD kernel where its shape assumptions hold (256-key groups, an even number of tiles per group);
-    // SSI_ATTN_DKV=1 (read per call: in-run A/B) keeps the round-1..3 kernel
-    const char* sel = getenv("SSI_ATTN_DKV");
-    // (plain causal rows only: packed rows keep the 128-key kernel, whose waves skip the tiles outside their keys' documents — at B = 2,
-    //  S = 8192 with documents of 440-1100 tokens the 256-key groups of this one, masking instead of skipping, took 409 us against 329)
+    // ssi_set_attn_impl(DKV, OLD) keeps the round-1..3 kernel
+    // (plain causal rows, or packed rows with a plan; packed rows without one keep the 128-key kernel, whose waves skip the tiles outside
+    //  their keys' documents — at B = 2, S = 8192 with documents of 440-1100 tokens the fixed 256-key groups of the plain form, masking
+    //  instead of skipping, took 409 us against 329)
     // ... and only where its 256-key workgroups (one per CU at a time) can be balanced over the 256 CUs: the heaviest one walks (S / 32) * rep
     // tiles, the chip's share per CU is the total over 256.  B = 8, S = 2048: 256 against 288; B = 2, S = 2048: 256 against 72 — there the
-    // 128-key kernel (two workgroups per CU, half the granularity) is faster.  SSI_ATTN_DKV=2 forces this kernel whatever the balance.
+    // 128-key kernel (two workgroups per CU, half the granularity) is faster.  Mode NEW forces this kernel whatever the balance.
     const int64_t ngrp2 = seq / 256, per0 = seq / 32;
     const int64_t total_tiles = batch * n_kv * rep * (ngrp2 * per0 - 8 * ngrp2 * (ngrp2 - 1) / 2);
-    const bool balanced = per0 * rep * 256 <= total_tiles * 23 / 20 || (sel && sel[0] == '2');
-    const bool v2 = !doc_end && seq % 256 == 0 && rep % 4 == 0 && (seq / 32) * rep <= DKV2_MAX_STEPS && balanced && !(sel && sel[0] == '1');
-    if (v2)
-        hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3((unsigned)(batch * n_kv * (seq / 256))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
-                           (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, rope, positions, (int)seq, n_heads, n_kv);
-    else {
-        // small launches: one workgroup per query head + a reduction, when the caller brought the workspace (SSI_ATTN_DKV=3: never)
+    const bool balanced = per0 * rep * 256 <= total_tiles * 23 / 20 || sel == SSI_ATTN_MODE_NEW;
+    const bool v2 = !doc_end && seq % 256 == 0 && rep % 4 == 0 && (seq / 32) * rep <= DKV2_MAX_STEPS && balanced && sel != SSI_ATTN_MODE_OLD;
+    if (ph && sel != SSI_ATTN_MODE_OLD) {
+        hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, dim3((unsigned)(ph[1] * n_kv)), dim3(256), 0, st, (const bf16_t*)qkv, ld, (const bf16_t*)dout, lse,
+                           delta, (bf16_t*)dqkv, rope, positions, (int)seq, n_heads, n_kv, reinterpret_cast<const int4*>(plan_dev + ph[2]));
+        used |= SSI_ATTN_USED_DKV2 | SSI_ATTN_USED_PLAN;
+    } else if (v2) {
+        hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, dim3((unsigned)(batch * n_kv * (seq / 256))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
+                           (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, rope, positions, (int)seq, n_heads, n_kv, (const int4*)nullptr);
+        used |= SSI_ATTN_USED_DKV2;
+    } else {
+        // small launches: one workgroup per query head + a reduction, when the caller brought the workspace (mode NO_HEAD_SPLIT: never)
         const int64_t want = ssi_attn_mfma_bwd_workspace_bytes(batch, seq, n_heads, n_kv);
-        if (want > 0 && workspace && workspace_bytes >= want && ((uintptr_t)workspace & 15) == 0 && !(sel && sel[0] == '3')) {
+        if (want > 0 && workspace && workspace_bytes >= want && ((uintptr_t)workspace & 15) == 0 && sel != SSI_ATTN_MODE_NO_HEAD_SPLIT) {
             const int slots = dkv_head_slots(batch, seq, n_heads, n_kv);
             hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3((unsigned)(batch * n_kv * (seq / 128) * slots)), dim3(256), 0, st, (const bf16_t*)qkv, ld,
                                (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, rope, positions, (int)seq, n_heads, n_kv, (float*)workspace,
@@ -1881,11 +2123,13 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
             SSI_LAUNCH_CHECK();
             hipLaunchKernelGGL(attn_dkv_head_reduce_kernel, dim3((unsigned)ssi_cdiv(batch * seq * n_kv * 32, 256)), dim3(256), 0, st,
                                (const float*)workspace, slots, batch * seq, n_kv, (bf16_t*)dqkv, ld, n_heads, rope, positions, (int)seq);
+            used |= SSI_ATTN_USED_HEAD_SPLIT;
         } else {
             hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3((unsigned)(batch * n_kv * (seq / 128))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
                                (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, doc_end, rope, positions, (int)seq, n_heads, n_kv, (float*)nullptr, rep);
         }
     }
     SSI_LAUNCH_CHECK();
+    ssi_attn_note_dispatch(used | 0x10000);  // bit 16: an MFMA backward ran
     return SSI_OK;
 }

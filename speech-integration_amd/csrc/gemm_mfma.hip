@@ -292,6 +292,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(int tiles_m, int
         INTERLEAVE(1);
         __builtin_amdgcn_sched_barrier(0);
     }
+    // nothing is in flight towards LDS any more (the last K-step's wait above saw to it); said once more where no branch can skip it, so
+    // that the listing shows it on every path to the end of the kernel (tools/kernel_lint.py, rule R3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     }
 
@@ -1148,6 +1151,10 @@ __device__ __forceinline__ void nt4_body(char* smem, int tiles_m, int tiles_n, i
             for (int q = 0; q < 4; ++q) { rdA1(S0[q], tileA(0), 0, 0, q); rdB1(S1[q], tileB(0), 0, 0, q); }
         }
     }
+    // Behind its last tile the fetch cursor kept requesting (valid memory, never consumed): those LDS-DMA requests must have landed before
+    // the workgroup ends — its LDS goes to whichever workgroup the CU runs next.  (Also waits for the last epilogue's stores: the kernel's
+    // end waits for them anyway.)
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the last workgroup to get here clears the scheduler slot for the launch that uses it next
     if (dynamic && tid == 0 && atomicAdd(&sched[8], 1) == G - 1) {  // plain stores: nobody reads the slot before this kernel has ended
         volatile int* vs = sched;

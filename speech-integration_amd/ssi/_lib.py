@@ -20,7 +20,11 @@ SSI_F32, SSI_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_MFMA_WG8 = 0, 1, 2, 3
 TILES_STATIC, TILES_DYNAMIC = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
+ATTN_KERNEL_DQ, ATTN_KERNEL_DKV = 0, 1
+ATTN_MODE_AUTO, ATTN_MODE_OLD, ATTN_MODE_NEW, ATTN_MODE_NO_HEAD_SPLIT = 0, 1, 2, 3
+ATTN_USED_DQ2, ATTN_USED_DKV2, ATTN_USED_HEAD_SPLIT, ATTN_USED_PLAN = 1, 2, 4, 8
+ATTN_PLAN_HEADER, ATTN_PLAN_FORCE = 16, 1
 
 # name -> (restype, argtypes); mirrors include/ssi_hip.h line by line
 _P = c_void_p
@@ -28,6 +32,8 @@ PROTOTYPES = {
     "ssi_abi_version": (c_int, []),
     "ssi_last_error": (c_char_p, []),
     "ssi_set_impl": (c_int, [c_int]),
+    "ssi_set_attn_impl": (c_int, [c_int, c_int]),
+    "ssi_attn_last_dispatch": (c_int, []),
     "ssi_embed_fwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, _P]),
     "ssi_embed_bwd_workspace_bytes": (c_int64, [c_int64]),
     "ssi_embed_bwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, _P, c_int64, _P]),
@@ -47,6 +53,10 @@ PROTOTYPES = {
     "ssi_attn_bwd_workspace_bytes": (c_int64, [c_int64, c_int64, c_int, c_int, c_int, c_int]),
     "ssi_attn_varlen_bwd_ws": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int, c_int, c_int,
                                        c_int, _P, c_int64, _P]),
+    "ssi_attn_plan_words": (c_int64, [c_int64, c_int64, c_int64]),
+    "ssi_attn_plan_build": (c_int64, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P, c_int64]),
+    "ssi_attn_varlen_bwd_plan": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int, c_int, c_int,
+                                         c_int, _P, c_int64, _P, _P, _P]),
     "ssi_doc_ranges": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P]),
     "ssi_swiglu_fwd": (c_int, [_P, _P, c_int64, c_int64, c_int, _P]),
     "ssi_swiglu_bwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P]),

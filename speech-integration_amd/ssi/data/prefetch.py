@@ -46,6 +46,8 @@ class DevicePrefetcher:
                     if not v.is_cuda:
                         v = v.pin_memory() if not v.is_pinned() else v
                     out[k] = v.to(self.device, non_blocking=True)
+                elif getattr(v, "is_attn_plan", False):  # ssi.attn_plan.AttnPlan: keeps its host copy, gains a device copy
+                    out[k] = v.to_device(self.device, non_blocking=True)
                 else:
                     out[k] = v
             ev = torch.cuda.Event()
@@ -92,6 +94,8 @@ class DevicePrefetcher:
                 if ev is not None:
                     torch.cuda.current_stream(self.device).wait_event(ev)  # stream-side wait: the host does not block
                     for v in batch.values():
+                        if getattr(v, "is_attn_plan", False):
+                            v = v.dev
                         if torch.is_tensor(v) and v.is_cuda:
                             v.record_stream(torch.cuda.current_stream(self.device))
                 yield batch

@@ -26,15 +26,25 @@ import torch
 from ..constants import CROSS_ENTROPY_IGNORE_IDX
 
 PACKED_KEYS = ("packed_tokens", "packed_labels", "packed_input_pos")
+PLAN_KEY = "packed_attn_plan"  # ssi.attn_plan.AttnPlan for the packed copy (or for a batch that arrived packed: "attn_plan")
 
 
 def unpad_batch(batch: dict[str, Any], *, pad_id: int = 0, ignore_index: int = CROSS_ENTROPY_IGNORE_IDX, multiple: int = 256,
-                padded_len: Optional[Callable[[int, int], int]] = None, min_saving: float = 0.03) -> dict[str, Any]:
+                padded_len: Optional[Callable[[int, int], int]] = None, min_saving: float = 0.03,
+                plan_fn: Optional[Callable[[torch.Tensor], Any]] = None) -> dict[str, Any]:
     """Add ``packed_tokens`` / ``packed_labels`` / ``packed_input_pos`` (int64 ``[1, T']``) to a right-padded ``{"tokens", "labels"}`` batch of
     host tensors, or return the batch unchanged when there is nothing to gain: already packed (``input_pos`` present), device tensors, no label
     that survives the shift (the reference's loss is 0/0 there and stays so), or fewer than ``min_saving`` of the rows the model would run
-    (``padded_len(B, S)`` rows per sequence: the model pads to whole tiles itself) saved."""
+    (``padded_len(B, S)`` rows per sequence: the model pads to whole tiles itself) saved.  ``plan_fn`` (the model's ``build_attn_plan``): called
+    with the HOST ``input_pos`` of the packed copy — or of a batch that arrived packed — its result (the work plan of the attention backward,
+    or ``None``) travels with the batch."""
     tokens, labels = batch.get("tokens"), batch.get("labels")
+    if plan_fn is not None and torch.is_tensor(batch.get("input_pos")) and not batch["input_pos"].is_cuda and batch.get("attn_plan") is None:
+        plan = plan_fn(batch["input_pos"])
+        if plan is not None:
+            batch = dict(batch)
+            batch["attn_plan"] = plan
+        return batch
     if (not torch.is_tensor(tokens) or not torch.is_tensor(labels) or tokens.is_cuda or labels.is_cuda or tokens.dim() != 2
             or tokens.shape != labels.shape or batch.get("input_pos") is not None or batch.get("mask") is not None or PACKED_KEYS[0] in batch):
         return batch
@@ -64,6 +74,10 @@ def unpad_batch(batch: dict[str, Any], *, pad_id: int = 0, ignore_index: int = C
     p_pos[0, o:] = idx[: t_packed - o] if t_packed - o <= S else torch.arange(t_packed - o)  # the tile tail: a document of its own, all ignored
     out = dict(batch)
     out["packed_tokens"], out["packed_labels"], out["packed_input_pos"] = p_tokens, p_labels, p_pos
+    if plan_fn is not None:
+        plan = plan_fn(p_pos)
+        if plan is not None:
+            out[PLAN_KEY] = plan
     return out
 
 
@@ -71,4 +85,7 @@ def loss_inputs(batch: dict[str, Any]) -> dict[str, Any]:
     """What ``compute_loss`` should see: the packed copy when the prefetcher made one, the batch itself otherwise."""
     if PACKED_KEYS[0] not in batch:
         return batch
-    return {"tokens": batch["packed_tokens"], "labels": batch["packed_labels"], "input_pos": batch["packed_input_pos"]}
+    out = {"tokens": batch["packed_tokens"], "labels": batch["packed_labels"], "input_pos": batch["packed_input_pos"]}
+    if batch.get(PLAN_KEY) is not None:
+        out["attn_plan"] = batch[PLAN_KEY]
+    return out

@@ -25,6 +25,8 @@ def batch_to_device(batch: dict, device: torch.device) -> None:
             batch_to_device(v, device)
         elif isinstance(v, torch.Tensor):
             batch[k] = v.to(device, non_blocking=True)
+        elif getattr(v, "is_attn_plan", False) and torch.device(device).type == "cuda":  # ssi.attn_plan.AttnPlan: host copy kept
+            batch[k] = v.to_device(device)
 
 
 def compute_dataset_loss(model, data_dev, loss_fn: Callable, epoch: int, global_step: int, steps_per_epoch: int,

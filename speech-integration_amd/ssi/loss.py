@@ -70,6 +70,8 @@ def compute_loss(batch: dict[str, Tensor], model, loss_fn: Callable) -> Tensor:
     if (hasattr(model, "fused_loss") and isinstance(loss_fn, CEWithChunkedOutputLoss) and batch.get("encoder_input") is None
             and (batch.get("mask") is None or batch.get("input_pos") is not None)):
         # packed batches (ssi/data/packed.py) carry input_pos: block-causal attention, per-document RoPE positions
+        if batch.get("attn_plan") is not None:  # made on the host beside a packed batch (ssi/attn_plan.py): pipelined attention backward
+            return model.fused_loss(batch["tokens"], labels, ignore_index, input_pos=batch.get("input_pos"), attn_plan=batch["attn_plan"])
         return model.fused_loss(batch["tokens"], labels, ignore_index, input_pos=batch.get("input_pos"))
     logits = model(
         tokens=batch["tokens"],

@@ -417,10 +417,28 @@ class HipLlamaDecoder(nn.Module):
         else:
             ops.gemm(layout, a, b, c, residual=residual)
 
-    def _forward_hidden(self, tokens: Tensor, save: bool, input_pos: Optional[Tensor] = None) -> Tensor:
+    def build_attn_plan(self, input_pos: Tensor, force: bool = False):
+        """Work plan of the attention backward for a packed batch (``ssi/attn_plan.py``) from a HOST ``input_pos`` [B, S] — what the data layer
+        calls in its prefetch thread; ``None`` where the pipelined kernels do not apply (device tensor, fp32 model, other head ratios, a length
+        the model would still have to pad, positions that are not document-relative, batches the library leaves to the round-1..3 kernels)."""
+        from . import attn_plan
+        if input_pos is None or input_pos.is_cuda or input_pos.dim() != 2 or not self._mfma_shapes() or self.head_dim != 64:
+            return None
+        B, S = input_pos.shape
+        if self.num_heads != 4 * self.num_kv_heads or self.padded_seq_len(B, S) != S or S % 128:
+            return None
+        return attn_plan.plan_from_input_pos(input_pos, self.num_heads, self.num_kv_heads, force=force)
+
+    def _forward_hidden(self, tokens: Tensor, save: bool, input_pos: Optional[Tensor] = None, attn_plan=None) -> Tensor:
         B, S = tokens.shape
         pos = ds = de = None
         self.position_errors = None
+        plan = None
+        if input_pos is not None and save:
+            if attn_plan is None and not input_pos.is_cuda:  # host positions: the plan costs no device sync (the trainer's prefetch thread
+                attn_plan = self.build_attn_plan(input_pos)   # brings one along with the batch instead)
+            if attn_plan is not None and attn_plan.matches(B, S, self.num_heads, self.num_kv_heads) and self._mfma_shapes():
+                plan = attn_plan.to_device(tokens.device)
         if input_pos is not None:
             if input_pos.shape != tokens.shape:
                 raise ValueError("input_pos must have the shape of tokens")
@@ -467,7 +485,7 @@ class HipLlamaDecoder(nn.Module):
         ops.rmsnorm_fwd(h, self.norm.scale, hn, rstdf, self.norm_eps)
         if save:
             self._fwd_generation += 1
-            self._saved = {"tok": tok, "B": B, "S": S, "gen": self._fwd_generation, "pos": pos, "ds": ds, "de": de}
+            self._saved = {"tok": tok, "B": B, "S": S, "gen": self._fwd_generation, "pos": pos, "ds": ds, "de": de, "plan": plan}
         return hn
 
     # ---- backward: decoder stack -------------------------------------------------------------------------------------
@@ -477,7 +495,7 @@ class HipLlamaDecoder(nn.Module):
             raise RuntimeError("HipLlamaDecoder: backward called for a forward whose activations were overwritten; "
                                "run backward before the next training forward")
         B, S, tok = sv["B"], sv["S"], sv["tok"]
-        pos, ds, de = sv["pos"], sv["ds"], sv["de"]
+        pos, ds, de, plan = sv["pos"], sv["ds"], sv["de"], sv.get("plan")
         T, D, I = B * S, self.embed_dim, self.intermediate_dim
         H, KV, hd, dt, A = self.num_heads, self.num_kv_heads, self.head_dim, self.dtype, self._arena
         L = self.num_layers
@@ -563,7 +581,7 @@ class HipLlamaDecoder(nn.Module):
             delta = A.get("delta", (B * H * S,), torch.float32)
             # attention backward with the backward of the RoPE rotation fused into its epilogues: dqkv arrives in pre-RoPE space
             ops.attn_bwd(qkv, att, datt, A.get(f"lse.{l}", (B * H * S,), torch.float32), dqkv, delta, B, S, H, KV, hd, ds, de,
-                         rope_table=self._rope, positions=pos, workspace=attn_ws)
+                         rope_table=self._rope, positions=pos, workspace=attn_ws, plan=plan)
             dgrad(dqkv, f"L{l}.wqkv", dxn)
             if not defer:
                 wgrad(dqkv, xn1, f"L{l}.wqkv")
@@ -653,11 +671,11 @@ class HipLlamaDecoder(nn.Module):
             raise _lib.HipLibraryError("tokens must live on the GPU (no CPU fallback)")
         return tokens
 
-    def forward_hidden(self, tokens: Tensor, input_pos: Optional[Tensor] = None) -> Tensor:
+    def forward_hidden(self, tokens: Tensor, input_pos: Optional[Tensor] = None, attn_plan=None) -> Tensor:
         """Final-normed hidden states [B, S, D] (autograd-aware)."""
         B, S = tokens.shape
         if torch.is_grad_enabled() and self.training:
-            hn = _DecoderFn.apply(self, tokens, self._anchor, input_pos)
+            hn = _DecoderFn.apply(self, tokens, self._anchor, input_pos, attn_plan)
         else:
             hn = self._forward_hidden(tokens, save=False, input_pos=input_pos)
         return hn.view(B, S, self.embed_dim)
@@ -684,10 +702,12 @@ class HipLlamaDecoder(nn.Module):
         return logits.float()
 
     def fused_loss(self, tokens: Tensor, shifted_labels: Tensor, ignore_index: int = CROSS_ENTROPY_IGNORE_IDX,
-                   input_pos: Optional[Tensor] = None) -> Tensor:
+                   input_pos: Optional[Tensor] = None, attn_plan=None) -> Tensor:
         """Mean NLL over non-ignored (already shifted) labels with the LM head + CE fused: equals
         ``CEWithChunkedOutputLoss()(model(tokens, input_pos=...), shifted_labels)`` of the reference for any chunk count.
-        ``input_pos`` ([B, S], restarting at 0 with every document): packed rows, block-causal attention."""
+        ``input_pos`` ([B, S], restarting at 0 with every document): packed rows, block-causal attention.  ``attn_plan``
+        (``build_attn_plan(input_pos)`` made on the host beside the batch): the attention backward then runs its pipelined kernels on the
+        packed rows; without one (and with ``input_pos`` on the device) the round-1..3 kernels run — same results to rounding."""
         tokens = self._check_inputs(tokens, None, None, None, input_pos)
         B, S = tokens.shape
         Sp = self.padded_seq_len(B, S)
@@ -700,7 +720,7 @@ class HipLlamaDecoder(nn.Module):
                 input_pos = torch.cat([input_pos.to(tokens.device), cont.clamp_(max=self._rope.shape[0] - 1)], dim=1)
         labels = shifted_labels.reshape(-1).contiguous()
         if torch.is_grad_enabled() and self.training:
-            return _FusedLossFn.apply(self, tokens, labels, ignore_index, self._anchor, input_pos)
+            return _FusedLossFn.apply(self, tokens, labels, ignore_index, self._anchor, input_pos, attn_plan)
         hn = self._forward_hidden(tokens, save=False, input_pos=input_pos)
         return self._ce_forward(hn, labels, ignore_index, write_grad=False)[0]
 
@@ -720,15 +740,15 @@ class HipLlamaDecoder(nn.Module):
 
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model: HipLlamaDecoder, tokens: Tensor, anchor: Tensor, input_pos: Optional[Tensor] = None) -> Tensor:
-        hn = model._forward_hidden(tokens, save=True, input_pos=input_pos)
+    def forward(ctx, model: HipLlamaDecoder, tokens: Tensor, anchor: Tensor, input_pos: Optional[Tensor] = None, attn_plan=None) -> Tensor:
+        hn = model._forward_hidden(tokens, save=True, input_pos=input_pos, attn_plan=attn_plan)
         ctx.model, ctx.gen = model, model._fwd_generation
         return hn
 
     @staticmethod
     def backward(ctx, d_hn: Tensor):
         ctx.model._backward_hidden(d_hn.contiguous(), ctx.gen)
-        return None, None, torch.zeros_like(ctx.model._anchor), None
+        return None, None, torch.zeros_like(ctx.model._anchor), None, None
 
 
 class _HeadLogitsFn(torch.autograd.Function):
@@ -754,8 +774,8 @@ class _FusedLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model: HipLlamaDecoder, tokens: Tensor, labels: Tensor, ignore_index: int, anchor: Tensor,
-                input_pos: Optional[Tensor] = None) -> Tensor:
-        hn = model._forward_hidden(tokens, save=True, input_pos=input_pos)
+                input_pos: Optional[Tensor] = None, attn_plan=None) -> Tensor:
+        hn = model._forward_hidden(tokens, save=True, input_pos=input_pos, attn_plan=attn_plan)
         loss, stats, dlogits = model._ce_forward(hn, labels, ignore_index, write_grad=True)
         ctx.model, ctx.gen = model, model._fwd_generation
         ctx.save_for_backward(hn, stats, dlogits)
@@ -772,7 +792,7 @@ class _FusedLossFn(torch.autograd.Function):
         alpha = (grad_out.to(torch.float32).reshape(1) / stats[2:3]).contiguous()
         d_hn = m._head_backward(dlogits, hn, alpha)
         m._backward_hidden(d_hn, ctx.gen)
-        return None, None, None, None, torch.zeros_like(m._anchor), None
+        return None, None, None, None, torch.zeros_like(m._anchor), None, None
 
 
 # --------------------------------------------------------------------------------------------------------------------

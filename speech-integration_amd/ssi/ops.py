@@ -11,12 +11,22 @@ from . import _lib
 from ._lib import GEMM_NN, GEMM_NT, GEMM_TN, check, dtype_code, ptr, stream_ptr
 
 __all__ = ["lmhead_ce_fwd", "lmhead_ce_bwd", "doc_ranges", "embed_fwd", "embed_bwd", "rmsnorm_fwd", "rmsnorm_bwd", "rope_", "attn_fwd", "attn_bwd", "attn_bwd_workspace_bytes", "swiglu_fwd",
-           "swiglu_bwd", "gemm", "gemm_splitk", "splitk_choice", "gemm_swiglu_fwd", "gemm_swiglu_bwd", "transpose", "ce_fwd", "ce_reduce", "count_tokens", "scale_", "sumsq", "adamw_step", "set_impl",
+           "swiglu_bwd", "gemm", "gemm_splitk", "splitk_choice", "gemm_swiglu_fwd", "gemm_swiglu_bwd", "transpose", "ce_fwd", "ce_reduce", "count_tokens", "scale_", "sumsq", "adamw_step", "set_impl", "set_attn_impl", "attn_last_dispatch",
            "GEMM_NT", "GEMM_NN", "GEMM_TN"]
 
 
 def set_impl(impl: int) -> int:
     return _lib.load().ssi_set_impl(impl)
+
+
+def set_attn_impl(which: int, mode: int) -> int:
+    """Which attention backward kernels may run (``_lib.ATTN_KERNEL_*`` x ``_lib.ATTN_MODE_*``; process-global); returns the previous mode."""
+    return _lib.load().ssi_set_attn_impl(which, mode)
+
+
+def attn_last_dispatch() -> int:
+    """Bit set of ``_lib.ATTN_USED_*``: the kernels the most recent MFMA attention backward of the process launched."""
+    return _lib.load().ssi_attn_last_dispatch()
 
 
 def _byte_ws(nbytes: int, like: Tensor) -> Tensor:
@@ -139,19 +149,30 @@ def attn_bwd_workspace_bytes(batch: int, seq: int, n_heads: int, n_kv: int, head
 
 def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, dqkv: Tensor, delta: Tensor, batch: int, seq: int,
              n_heads: int, n_kv: int, head_dim: int, doc_start: Optional[Tensor] = None, doc_end: Optional[Tensor] = None,
-             rope_table: Optional[Tensor] = None, positions: Optional[Tensor] = None, workspace: Optional[Tensor] = None) -> None:
+             rope_table: Optional[Tensor] = None, positions: Optional[Tensor] = None, workspace: Optional[Tensor] = None, plan=None) -> None:
     """dqkv of causal (or block-causal) GQA attention.  With ``rope_table`` the q / k parts come back in pre-RoPE space (the
-    backward of ``rope_`` fused in), positions as in ``rope_``.  ``workspace`` (bytes, see ``attn_bwd_workspace_bytes``): optional."""
+    backward of ``rope_`` fused in), positions as in ``rope_``.  ``workspace`` (bytes, see ``attn_bwd_workspace_bytes``): optional.
+    ``plan`` (``ssi.attn_plan.AttnPlan`` on the device, packed rows only): the pipelined kernels take the documents' work from it."""
     assert qkv.stride(1) == 1 and dqkv.stride() == qkv.stride() and out.is_contiguous() and dout.is_contiguous()
     assert delta.dtype == torch.float32 and delta.numel() >= batch * n_heads * seq
     ds, de = _doc_ptrs(doc_start, doc_end, batch * seq)
-    if workspace is not None:
-        assert workspace.is_contiguous() and rope_table is None or (rope_table.dtype == torch.float32 and rope_table.is_contiguous())
+    if workspace is not None or plan is not None:
+        assert workspace is None or (workspace.is_contiguous() and workspace.dtype == torch.uint8)
+        assert rope_table is None or (rope_table.dtype == torch.float32 and rope_table.is_contiguous() and rope_table.shape[1] * 2 == head_dim)
         assert positions is None or (positions.dtype == torch.int32 and positions.numel() == batch * seq)
+        ws_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+        table_len = rope_table.shape[0] if rope_table is not None else 0
+        if plan is not None:
+            assert ds is not None and plan.dev is not None and plan.dev.device == qkv.device and plan.matches(batch, seq, n_heads, n_kv)
+            check(_lib.load().ssi_attn_varlen_bwd_plan(ptr(qkv), qkv.stride(0), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), ds, de,
+                                                       ptr(rope_table), table_len, ptr(positions), batch, seq, n_heads, n_kv, head_dim,
+                                                       dtype_code(qkv.dtype), ptr(workspace), ws_bytes, ptr(plan.dev), plan.host.data_ptr(),
+                                                       stream_ptr()), "ssi_attn_varlen_bwd_plan")
+            return
         check(_lib.load().ssi_attn_varlen_bwd_ws(ptr(qkv), qkv.stride(0), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), ds, de,
-                                                 ptr(rope_table), rope_table.shape[0] if rope_table is not None else 0, ptr(positions), batch,
-                                                 seq, n_heads, n_kv, head_dim, dtype_code(qkv.dtype), ptr(workspace),
-                                                 workspace.numel() * workspace.element_size(), stream_ptr()), "ssi_attn_varlen_bwd_ws")
+                                                 ptr(rope_table), table_len, ptr(positions), batch,
+                                                 seq, n_heads, n_kv, head_dim, dtype_code(qkv.dtype), ptr(workspace), ws_bytes, stream_ptr()),
+              "ssi_attn_varlen_bwd_ws")
         return
     if rope_table is None:
         check(_lib.load().ssi_attn_varlen_bwd(ptr(qkv), qkv.stride(0), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), ds, de, batch,

@@ -364,7 +364,7 @@ class Trainer:
         from .data.unpad import unpad_batch
         tiles = getattr(self.model, "_mfma_shapes", lambda: False)()  # the MFMA kernels walk whole 256-row tiles; the generic ones take any length
         return partial(unpad_batch, pad_id=self.tokenizer.pad_id, ignore_index=self.loss_fn.ignore_index, padded_len=self.model.padded_seq_len,
-                       multiple=256 if tiles else 1)
+                       multiple=256 if tiles else 1, plan_fn=getattr(self.model, "build_attn_plan", None))
 
     def _train_epoch(self, epoch: int, batches_to_skip: int = 0) -> None:
         window = self.cfg.gradient_accumulation_steps

@@ -58,3 +58,27 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_the_launch_path_reads_no_environment():
+    """Process-global switches are atomics behind setters (``ssi_set_impl``, ``ssi_set_gemm_tile_order``, ``ssi_set_attn_impl``); the only
+    ``getenv`` in the native sources is the one-time initialiser of the attention switches (C++ static initialisation), and the header lists
+    them under "PROCESS-GLOBAL state"."""
+    csrc = os.path.join(ROOT, "speech-integration_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            for n, line in enumerate(open(os.path.join(csrc, f)), 1):
+                if re.search(r"\bgetenv\s*\(", line) and not line.lstrip().startswith("//"):
+                    hits.append((f, n, line.strip()))
+    assert len(hits) == 1 and hits[0][0] == "attention_mfma.hip" and "const char* s = getenv(name)" in hits[0][2], hits
+    src = open(os.path.join(csrc, "attention_mfma.hip")).read()
+    assert re.search(r"static std::atomic<int> modes\[2\] = \{\{attn_env_mode\(", src), "the environment is read under static initialisation only"
+    header = open(os.path.join(ROOT, "include", "ssi_hip.h")).read()
+    assert "ssi_set_attn_impl" in header.split("#ifndef SSI_HIP_H")[0], "the header's PROCESS-GLOBAL list names the attention switches"
+    from ssi import _lib
+    lib = _lib.load()
+    prev = lib.ssi_set_attn_impl(_lib.ATTN_KERNEL_DQ, _lib.ATTN_MODE_OLD)
+    assert lib.ssi_set_attn_impl(_lib.ATTN_KERNEL_DQ, prev) == _lib.ATTN_MODE_OLD
+    assert lib.ssi_set_attn_impl(_lib.ATTN_KERNEL_DQ, 7) == prev and lib.ssi_set_attn_impl(5, 0) == -1   # invalid mode only reads, invalid kernel -> -1
+    assert lib.ssi_attn_last_dispatch() == 0

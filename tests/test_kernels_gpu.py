@@ -527,9 +527,25 @@ def test_attention_mfma_fwd_bwd(ops, B, S, H, KV):
         ops.set_impl(prev)
 
 
-@pytest.mark.parametrize("B,S,H,KV", [(3, 256, 4, 1), (2, 512, 8, 2), (1, 1024, 32, 8), (2, 2048, 8, 2)])
+@pytest.fixture
+def attn_impl(ops):
+    """Switch the attention backward kernels through the ABI's setter (``ssi_set_attn_impl``) and put the previous modes back afterwards."""
+    from ssi import _lib
+    saved = {}
+
+    def choose(which, mode):
+        prev = ops.set_attn_impl(which, mode)
+        saved.setdefault(which, prev)
+
+    yield choose
+    for which, mode in saved.items():
+        ops.set_attn_impl(which, mode)
+
+
+@pytest.mark.parametrize("B,S,H,KV", [(3, 256, 4, 1), (2, 512, 8, 2), (1, 1024, 32, 8), (2, 2048, 8, 2), (8, 4096, 32, 8), (1, 8192, 8, 2),
+                                      (5, 1280, 4, 1)])
 @pytest.mark.parametrize("fused_rope", [False, True])
-def test_attention_dkv_pipelined_kernel_matches_the_128_key_kernel(ops, B, S, H, KV, fused_rope, monkeypatch):
+def test_attention_dkv_pipelined_kernel_matches_the_128_key_kernel(ops, B, S, H, KV, fused_rope, attn_impl):
     """Round 4: dK / dV on the one-wave-per-SIMD pipelined kernel (256-key groups, masked diagonal tiles first) against the round-1..3
     kernel on the same inputs.  Same products and operands, another order of the sums over the query tiles: equal to fp32 rounding of
     the sums (the bf16 results differ by at most one bf16 step), the dQ block untouched, and reproducible run to run.  S = 256 has no
@@ -552,9 +568,10 @@ def test_attention_dkv_pipelined_kernel_matches_the_128_key_kernel(ops, B, S, H,
         ops.attn_fwd(x, out, lse, B, S, H, KV, hd)
         res = {}
         for sel in ("1", "2", "2"):   # 1 = the 128-key kernel, 2 = the pipelined kernel even where its workgroups cannot fill the chip (small cases)
-            monkeypatch.setenv("SSI_ATTN_DKV", sel)
+            attn_impl(_lib.ATTN_KERNEL_DKV, int(sel))
             d = torch.full_like(x, float("nan"))
             ops.attn_bwd(x, out, dout, lse, d, delta, B, S, H, KV, hd, rope_table=table, positions=pos)
+            assert bool(ops.attn_last_dispatch() & _lib.ATTN_USED_DKV2) == (sel == "2"), "the dispatcher ignored the switch"
             res.setdefault(sel, []).append(d.cpu().float())
     finally:
         ops.set_impl(prev)
@@ -570,9 +587,10 @@ def test_attention_dkv_pipelined_kernel_matches_the_128_key_kernel(ops, B, S, H,
 
 
 @pytest.mark.parametrize("B,S,H,KV", [(1, 512, 4, 1), (3, 512, 8, 2), (2, 1024, 32, 8), (1, 2048, 8, 2), (8, 2048, 32, 8),
-                                      (2, 128, 8, 2), (1, 256, 4, 1), (3, 384, 4, 1), (2, 2048, 32, 8)])
+                                      (2, 128, 8, 2), (1, 256, 4, 1), (3, 384, 4, 1), (2, 2048, 32, 8), (8, 4096, 32, 8), (1, 8192, 8, 2),
+                                      (3, 640, 4, 1), (1, 1152, 8, 2)])
 @pytest.mark.parametrize("fused_rope", [False, True])
-def test_attention_dq_pipelined_persistent_kernel_matches_the_round_1_kernel(ops, B, S, H, KV, fused_rope, monkeypatch):
+def test_attention_dq_pipelined_persistent_kernel_matches_the_round_1_kernel(ops, B, S, H, KV, fused_rope, attn_impl):
     """Round 4: dQ on the one-wave-per-SIMD pipelined kernel with persistent workgroups (8 query blocks of 64 per workgroup, the next block's
     Q / dO / O rows and the RoPE table rows staged through LDS) against the round-1..3 kernel on the same inputs.  Same products, same order
     of the sums over the key tiles; the exponent is one fma of the unscaled S (x log2(e)/8) where the old kernel scales Q by 1/8 first —
@@ -580,8 +598,9 @@ def test_attention_dq_pipelined_persistent_kernel_matches_the_round_1_kernel(ops
     and the dK / dV blocks must be IDENTICAL, the result reproducible.  S = 512: one workgroup per (batch, kv head) with all 8 blocks, B * KV
     not a multiple of 8 (second case: the plain workgroup -> pair map); S = 1024 / 2048: 2 / 4 workgroups per pair in zig-zag groups; the
     fifth case is the step's shape; S = 128, 256, 384: 2, 4 and 2 blocks per workgroup (a single pair of blocks; 3 workgroups per pair); the
-    last is the reference's default SFT micro-batch, 2 x 2048, where the dispatcher takes 2 blocks per workgroup (256 workgroups).  Those two
-    the dispatcher picks by itself, the others are forced (SSI_ATTN_DQ=2)."""
+    ninth is the reference's default SFT micro-batch, 2 x 2048, where the dispatcher takes 2 blocks per workgroup (256 workgroups).  Those two
+    and (8, 4096) — BASELINE config C's one-GPU batch — the dispatcher picks by itself, the others are forced (mode NEW); S = 640 and 1152: 10
+    and 18 query blocks, i.e. 2 blocks per workgroup with 5 and 9 workgroups per pair (odd counts)."""
     from ssi import _lib
     hd = 64
     qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=81)
@@ -595,11 +614,12 @@ def test_attention_dq_pipelined_persistent_kernel_matches_the_round_1_kernel(ops
         lse = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
         ops.attn_fwd(x, out, lse, B, S, H, KV, hd)
         res = {}
-        for sel in ("1", "2", "2") + (("0",) if (B, S) in ((8, 2048), (2, 2048)) else ()):
-            monkeypatch.setenv("SSI_ATTN_DQ", sel)
+        for sel in ("1", "2", "2") + (("0",) if (B, S) in ((8, 2048), (2, 2048), (8, 4096)) else ()):
+            attn_impl(_lib.ATTN_KERNEL_DQ, int(sel))
             d = torch.full_like(x, float("nan"))
             delta = torch.full_like(lse, float("nan"))
             ops.attn_bwd(x, out, dout, lse, d, delta, B, S, H, KV, hd, rope_table=table)
+            assert bool(ops.attn_last_dispatch() & _lib.ATTN_USED_DQ2) == (sel != "1"), "the dispatcher ignored the switch"
             res.setdefault(sel, []).append((d.cpu().float(), delta.cpu()))
     finally:
         ops.set_impl(prev)
@@ -660,6 +680,168 @@ def test_attention_backward_with_workspace_splits_dkv_over_the_query_heads(ops, 
     assert not torch.equal(a, b), "the head-split form did not run"
     assert float((a - b).norm() / a.norm()) <= 3e-4
     assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max())
+
+
+@pytest.mark.parametrize("B,S,H,KV", [(8, 2048, 32, 8), (1, 4096, 32, 8), (8, 4096, 32, 8), (1, 8192, 32, 8), (1, 16384, 32, 8), (2, 2048, 32, 8),
+                                      (3, 640, 4, 1)])
+def test_attention_pipelined_backward_kernels_against_fp32_sdpa(ops, B, S, H, KV, attn_impl):
+    """Round 5 (the round-4 review: the pipelined kernels met an fp32 reference only through whole-model tests): attn_bwd_dq2_kernel and
+    attn_bwd_dkv2_kernel, FORCED (mode NEW) and the dispatch asserted, against torch SDPA in fp32 on the same bf16 inputs, with the tolerances of
+    test_attention_mfma_fwd_bwd — at every kind of shape the dispatcher sends them: the headline batch; BASELINE config C's rows at B = 1 and at
+    its one-GPU batch B = 8 (16 key groups, 512-entry tile tables); S = 8192; S = 16 384 (DKV2_MAX_STEPS: the tile table full to its last
+    entry); the reference's default micro-batch 2 x 2048 (2 query blocks per dQ workgroup); an odd number of workgroups per pair."""
+    from ssi import _lib
+    hd = 64
+    qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=131)
+    qkv[S // 2 + 3, H * hd: H * hd + hd] *= 6.0
+    qkv[S - 5, :hd] *= 4.0
+    do = rnd(B * S, H * hd, dtype=torch.bfloat16, seed=132)
+    qr = qkv.float().clone().requires_grad_(True)
+    oref = _sdpa_ref(qr, B, S, H, KV, hd)
+    oref.backward(do.float())
+    prev = ops.set_impl(_lib.IMPL_MFMA)
+    try:
+        attn_impl(_lib.ATTN_KERNEL_DQ, _lib.ATTN_MODE_NEW)
+        attn_impl(_lib.ATTN_KERNEL_DKV, _lib.ATTN_MODE_NEW)
+        x, dout = qkv.to(DEV), do.to(DEV)
+        out = torch.full((B * S, H * hd), float("nan"), dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+        ops.attn_fwd(x, out, lse, B, S, H, KV, hd)
+        res = []
+        for _ in range(2):
+            dqkv = torch.full_like(x, float("nan"))
+            ops.attn_bwd(x, out, dout, lse, dqkv, torch.empty(B * H * S, dtype=torch.float32, device=DEV), B, S, H, KV, hd)
+            used = ops.attn_last_dispatch()
+            assert used & _lib.ATTN_USED_DQ2 and not used & _lib.ATTN_USED_PLAN, hex(used)
+            assert bool(used & _lib.ATTN_USED_DKV2) == (S % 256 == 0), hex(used)   # (256-key groups: S = 640 keeps the 128-key kernel)
+            res.append(dqkv.cpu().float())
+    finally:
+        ops.set_impl(prev)
+    dqkv = res[0]
+    assert torch.equal(res[0], res[1]), "not reproducible"
+    assert torch.isfinite(dqkv).all()
+    torch.testing.assert_close(out.cpu().float(), oref.detach(), rtol=2e-2, atol=2e-2)
+    scale = float(qr.grad.abs().max())
+    assert float((dqkv - qr.grad).abs().max()) <= 3e-2 * scale
+    for name, lo, hi in (("dq", 0, H * hd), ("dk", H * hd, (H + KV) * hd), ("dv", (H + KV) * hd, (H + 2 * KV) * hd)):
+        rel = float((dqkv[:, lo:hi] - qr.grad[:, lo:hi]).norm() / qr.grad[:, lo:hi].norm())
+        assert rel <= 1.5e-2, (name, rel)
+
+
+def _random_documents(S, seed, lo, hi):
+    g = torch.Generator().manual_seed(seed)
+    lens, left = [], S
+    while left > 0:
+        n = min(left, int(torch.randint(lo, hi + 1, (1,), generator=g)))
+        lens.append(n)
+        left -= n
+    return lens
+
+
+PLAN_CASES = [
+    (2, 256, 4, 1, [[100, 37, 119], [1, 63, 64, 128]]),              # boundaries off every tile size; a 1-token document
+    (1, 512, 4, 1, [[512]]),                                         # one document: the plan's items are the plain kernels' workgroups
+    (1, 384, 4, 1, [[5] * 76 + [4]]),                                # tiny documents: many items per 64 rows
+    (1, 2048, 8, 2, [[700, 31, 1100, 217]]),                         # BASELINE-E-like documents
+    (2, 1024, 8, 2, [[256, 512, 256], [33, 31, 64, 896]]),           # documents on the 256 / 64 / 32 grids, and starting at 33
+    (1, 4096, 8, 2, [_random_documents(4096, 5, 1, 700)]),
+    (2, 2048, 32, 8, [_random_documents(2048, 6, 200, 900), _random_documents(2048, 7, 30, 400)]),
+    (1, 11520, 32, 8, [[1807, 2038, 1909, 1924, 1500, 2048, 294]]),  # a right-padded 8 x 2048 batch after the unpadding
+]
+
+
+@pytest.mark.parametrize("B,S,H,KV,rows", PLAN_CASES, ids=[f"{c[0]}x{c[1]}-{len(c[4][0])}docs" for c in PLAN_CASES])
+@pytest.mark.parametrize("fused_rope", [False, True])
+def test_attention_plan_kernels_on_packed_rows(ops, B, S, H, KV, rows, fused_rope, attn_impl):
+    """Round 5: packed rows on the pipelined backward kernels (document-aware forms: attn_bwd_dq2_kernel<0, true>, attn_bwd_dkv2_kernel<true>)
+    from a host-built work plan (ssi_attn_plan_build): against torch SDPA with the dense block mask in fp32, against the plan-less call (the
+    round-1..3 kernels: another order of the fp32 sums), reproducible, the dispatch asserted; with the fused RoPE backward the positions are
+    document-relative (the plan's assumption).  Documents must not leak: perturbing one leaves the others' gradients bit-identical."""
+    from ssi import _lib, attn_plan
+    hd = 64
+    qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=141)
+    do = rnd(B * S, H * hd, dtype=torch.bfloat16, seed=142)
+    ds, de = (t.to(DEV) for t in _doc_arrays(rows, S))
+    plan = attn_plan.plan_from_seq_lens(rows, H, KV, force=True)
+    assert plan is not None and plan.matches(B, S, H, KV)
+    # every key belongs to exactly one dK/dV item, every query to exactly one dQ item
+    seen_k, seen_q = torch.zeros(B, S, dtype=torch.int32), torch.zeros(B, S, dtype=torch.int32)
+    for b, k0, d0, d1 in plan.dkv_items():
+        seen_k[b, max(k0, d0):min(k0 + 256, d1)] += 1
+    for grp in plan.dq_groups():
+        for b, q0, d0, d1 in grp:
+            seen_q[b, max(q0, d0):min(q0 + 64, d1)] += 1
+    assert bool((seen_k == 1).all()) and bool((seen_q == 1).all())
+    plan = plan.to_device(DEV)
+    table = pos = None
+    if fused_rope:
+        table = rnd(max(max(r) for r in rows) + 3, hd // 2, 2, dtype=torch.float32, seed=143).to(DEV)   # no longer than the longest document needs
+        pos = torch.cat([torch.cat([torch.arange(n) for n in lens]) for lens in rows]).to(torch.int32).to(DEV)
+
+    def run(x, plan_):
+        out = torch.full((B * S, H * hd), float("nan"), dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+        ops.attn_fwd(x, out, lse, B, S, H, KV, hd, ds, de)
+        d = torch.full_like(x, float("nan"))
+        ops.attn_bwd(x, out, do.to(DEV), lse, d, torch.empty(B * H * S, dtype=torch.float32, device=DEV), B, S, H, KV, hd, ds, de, rope_table=table,
+                     positions=pos, plan=plan_)
+        used = ops.attn_last_dispatch()
+        want = _lib.ATTN_USED_DQ2 | _lib.ATTN_USED_DKV2 | _lib.ATTN_USED_PLAN
+        assert (used & want) == (want if plan_ is not None else 0), hex(used)
+        return d.cpu().float()
+
+    prev = ops.set_impl(_lib.IMPL_MFMA)
+    try:
+        new, new2, old = run(qkv.to(DEV), plan), run(qkv.to(DEV), plan), run(qkv.to(DEV), None)
+        n0 = rows[0][0]
+        if n0 < S:
+            pert = qkv.clone()
+            pert[:n0] = rnd(n0, qkv.shape[1], dtype=torch.bfloat16, seed=144)
+            newp = run(pert.to(DEV), plan)
+    finally:
+        ops.set_impl(prev)
+    assert torch.isfinite(new).all(), f"{int((~torch.isfinite(new)).sum())} non-finite gradients (rows {torch.nonzero(~torch.isfinite(new).all(dim=1)).flatten()[:8].tolist()})"
+    assert torch.equal(new, new2), "not reproducible"
+    for name, lo, hi in (("dq", 0, H * hd), ("dk", H * hd, (H + KV) * hd), ("dv", (H + KV) * hd, (H + 2 * KV) * hd)):
+        a, b = old[:, lo:hi], new[:, lo:hi]
+        assert float((a - b).norm() / a.norm()) <= 3e-4, name
+        assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max()), f"{name}: more than a bf16 step apart"
+    if n0 < S:
+        assert torch.equal(newp[n0:], new[n0:]) and not torch.equal(newp[:n0], new[:n0]), "documents leak into each other"
+    if not fused_rope and B * S <= 8192:
+        qr = qkv.float().clone().requires_grad_(True)
+        _sdpa_block_ref(qr, B, S, H, KV, hd, rows).backward(do.float())
+        scale = float(qr.grad.abs().max())
+        assert float((new - qr.grad).abs().max()) <= 3e-2 * scale
+        assert float((new - qr.grad).norm() / qr.grad.norm()) <= 1.5e-2
+
+
+def test_attention_plan_builder_declines_what_the_old_kernels_do_better(ops):
+    """ssi_attn_plan_build returns no plan for head ratios other than 4, mostly tiny documents, a few long documents and nothing else (there
+    the 128-key kernel's split over the query heads wins), documents beyond the tile table; a plan that belongs to another batch is refused
+    by the launch; documents that do not tile the rows are an error."""
+    from ssi import attn_plan
+    assert attn_plan.plan_from_seq_lens([[700, 31, 1100, 217]], 8, 4) is None
+    assert attn_plan.plan_from_seq_lens([[5] * 76 + [4]], 4, 1) is None
+    assert attn_plan.plan_from_seq_lens([[2048], [2048]], 32, 8) is None
+    assert attn_plan.plan_from_seq_lens([[2048]] * 8, 32, 8) is not None
+    assert attn_plan.plan_from_seq_lens([[32768]], 32, 8) is None
+    assert attn_plan.plan_from_seq_lens([[1807, 2038, 1909, 1924, 1500, 2048, 294]], 32, 8) is not None
+    t = lambda x: torch.tensor(x, dtype=torch.int32)  # noqa: E731
+    with pytest.raises(ValueError):
+        attn_plan.build_plan(t([0, 0]), t([0, 100]), t([90, 256]), 1, 256, 4, 1)     # a gap
+    B, S, H, KV, hd = 1, 512, 4, 1, 64
+    plan = attn_plan.plan_from_seq_lens([[200, 312]], H, KV, force=True).to_device(DEV)
+    other = attn_plan.plan_from_seq_lens([[100, 156]], H, KV, force=True).to_device(DEV)
+    x = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=151).to(DEV)
+    ds, de = (u.to(DEV) for u in _doc_arrays([[200, 312]], S))
+    out = torch.empty(B * S, H * hd, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+    ops.attn_fwd(x, out, lse, B, S, H, KV, hd, ds, de)
+    with pytest.raises(AssertionError):
+        ops.attn_bwd(x, out, out, lse, torch.empty_like(x), torch.empty_like(lse), B, S, H, KV, hd, ds, de, plan=other)
+    with pytest.raises(AssertionError):
+        ops.attn_bwd(x, out, out, lse, torch.empty_like(x), torch.empty_like(lse), B, S, H, KV, hd, None, None, plan=plan)
 
 
 def _doc_arrays(seq_lens_rows, S):

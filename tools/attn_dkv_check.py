@@ -1,4 +1,4 @@
-"""dK / dV kernels side by side in ONE process (SSI_ATTN_DKV is read per call): the round-4 pipelined kernel against the round-1..3 kernel —
+"""dK / dV kernels side by side in ONE process (ssi_set_attn_impl switches the kernel between calls): the round-4 pipelined kernel against the round-1..3 kernel —
 agreement, run-to-run reproducibility, time.  B=8, S=2048, H=32, KV=8, hd=64 as in the step; `packed` adds documents of 440-1100 tokens."""
 import os, sys, torch
 sys.path.insert(0, 'speech-integration_amd')
@@ -27,7 +27,7 @@ if packed:
     kw = dict(doc_start=ds, doc_end=de)
 ops.attn_fwd(qkv, out, lse, B, S, H, KV, hd, **kw)
 def bwd(sel):
-    os.environ['SSI_ATTN_DKV'] = sel
+    ops.set_attn_impl(1, int(sel))
     d = torch.zeros_like(qkv)
     ops.attn_bwd(qkv, out, dout, lse, d, delta, B, S, H, KV, hd, **kw)
     torch.cuda.synchronize()
@@ -39,7 +39,7 @@ a, b_ = old[:, kv].float(), new[:, kv].float()
 print(f'dK/dV new vs old: max abs {float((a - b_).abs().max()):.3e}  rel fro {float((a - b_).norm() / a.norm()):.3e}  '
       f'nan {int(torch.isnan(b_).sum())}  |old| {float(a.norm()):.3e}')
 def t(sel, iters=20):
-    os.environ['SSI_ATTN_DKV'] = sel
+    ops.set_attn_impl(1, int(sel))
     d = torch.empty_like(qkv)
     f = lambda: ops.attn_bwd(qkv, out, dout, lse, d, delta, B, S, H, KV, hd, **kw)
     for _ in range(3): f()

@@ -1,4 +1,4 @@
-"""dQ kernels side by side in ONE process (SSI_ATTN_DQ is read per call): the round-4 pipelined kernel against the round-1..3 kernel —
+"""dQ kernels side by side in ONE process (ssi_set_attn_impl switches the kernel between calls): the round-4 pipelined kernel against the round-1..3 kernel —
 agreement (and both against an fp32 torch reference on a slice), run-to-run reproducibility, time.  B=8, S=2048, H=32, KV=8, hd=64 as in
 the step.  The dK / dV kernel is the same in both runs, so the difference of the two totals is the dQ kernels' difference."""
 import os, sys, torch
@@ -13,7 +13,7 @@ lse = torch.empty(B * H * S, device='cuda', dtype=torch.float32)
 dout = torch.randn(T, H * hd, device='cuda').bfloat16()
 ops.attn_fwd(qkv, out, lse, B, S, H, KV, hd)
 def bwd(sel):
-    os.environ['SSI_ATTN_DQ'] = sel
+    ops.set_attn_impl(0, int(sel))
     d = torch.zeros_like(qkv)
     delta = torch.zeros_like(lse)
     ops.attn_bwd(qkv, out, dout, lse, d, delta, B, S, H, KV, hd)
@@ -38,7 +38,7 @@ for name, d in (('old', old), ('new', new)):
     x = d[:S, hh * hd:(hh + 1) * hd].float()
     print(f'dQ {name} vs fp32 torch (b 0, head {hh}): rel fro {float((x - Q.grad).norm() / Q.grad.norm()):.3e}')
 def t(sel, iters=20):
-    os.environ['SSI_ATTN_DQ'] = sel
+    ops.set_attn_impl(0, int(sel))
     d = torch.empty_like(qkv); delta = torch.empty_like(lse)
     f = lambda: ops.attn_bwd(qkv, out, dout, lse, d, delta, B, S, H, KV, hd)
     for _ in range(3): f()
