@@ -337,6 +337,9 @@ def main() -> int:
     ap.add_argument("--no-unpad", action="store_true",
                     help="with --padded: run the right-padded rows as they are (the round-1..3 behaviour) instead of dropping the padding on the "
                          "host as the trainer's prefetch thread does (ssi/data/unpad.py)")
+    ap.add_argument("--no-attn-plan", action="store_true",
+                    help="with --packed / --padded: no work plan for the attention backward (ssi/attn_plan.py), i.e. the round-1..3 kernels on the "
+                         "packed rows — the in-run comparison partner of the plan")
     ap.add_argument("--through-trainer", action="store_true",
                     help="secondary line: the workload through Trainer.setup()/train() (the scripts/train_sft.py path) at grad-accum 1 and 4; "
                          "one GPU.  Not the headline line.")
@@ -393,15 +396,21 @@ def main() -> int:
     pad_id = lcfg._base_vocab_size_txt + lcfg.n_dsus + 2 + 4
 
     n_total = args.warmup + args.steps
+    # host-side preparation of a batch, as the trainer's prefetch thread does it before the batch is copied over (outside the timed region like
+    # every preparation of a resident batch): the padding dropped, the work plan of the attention backward built from the HOST input_pos
+    plan_fn = None if args.no_attn_plan else model.build_attn_plan
+    to_dev = lambda v: v.to(device) if torch.is_tensor(v) else (v.to_device(device) if getattr(v, "is_attn_plan", False) else v)  # noqa: E731
+    from ssi.data import loss_inputs, unpad_batch
     if args.packed:
-        batches = [{k: (v.to(device) if torch.is_tensor(v) else v)
-                    for k, v in synthetic_packed_batch(args.batch, args.seq, args.n_dsus, seed=42_831 + i, rank=rank).items()} for i in range(min(n_total, 4))]
+        host = [synthetic_packed_batch(args.batch, args.seq, args.n_dsus, seed=42_831 + i, rank=rank) for i in range(min(n_total, 4))]
+        if plan_fn is not None:
+            host = [unpad_batch(b, pad_id=pad_id, plan_fn=plan_fn) for b in host]   # (a batch that arrives packed only gains its plan)
     else:
-        from ssi.data import loss_inputs, unpad_batch
         host = [synthetic_batch(args.batch, args.seq, args.n_dsus, rank=rank, index=i % 4, fixed_len=not args.padded) for i in range(min(n_total, 4))]
-        if args.padded and not args.no_unpad:  # what the trainer's prefetch thread does to a right-padded batch before it is copied over
-            host = [unpad_batch(b, pad_id=pad_id, padded_len=model.padded_seq_len) for b in host]
-        batches = [{k: v.to(device) for k, v in b.items()} for b in host]
+        if args.padded and not args.no_unpad:
+            host = [unpad_batch(b, pad_id=pad_id, padded_len=model.padded_seq_len, plan_fn=plan_fn) for b in host]
+    batches = [{k: to_dev(v) for k, v in b.items()} for b in host]
+    n_plans = sum(1 for b in batches if any(getattr(v, "is_attn_plan", False) for v in b.values()))
     if os.environ.get("SSI_BENCH_TILE_ORDER"):  # diagnostic: price of the data-parallel tile order on one GPU ("dynamic" | "static")
         from ssi import ops as _ops
         _ops.set_gemm_tile_order(dynamic=os.environ["SSI_BENCH_TILE_ORDER"] == "dynamic")
@@ -478,6 +487,14 @@ def main() -> int:
                                    + (", padding dropped on the host (ssi/data/unpad.py)" if args.padded and not args.no_unpad else ""),
                        "global_batch": args.batch * world * ga, "seq_len": args.seq, "parallelism": f"dp{world}", "last_loss": loss},
         }
+        # which attention backward kernels the last micro-batch took (ssi_attn_last_dispatch): a secondary line says what path its number is from
+        from ssi import _lib as _l, ops as _o
+        used = _o.attn_last_dispatch()
+        out["attention_backward"] = {
+            "dq": ("attn_bwd_dq2_kernel<plan>" if used & _l.ATTN_USED_PLAN else f"attn_bwd_dq2_kernel<{(used >> 8) & 15}>") if used & _l.ATTN_USED_DQ2 else "attn_bwd_dq_kernel",
+            "dkv": ("attn_bwd_dkv2_kernel<plan>" if used & _l.ATTN_USED_PLAN else "attn_bwd_dkv2_kernel") if used & _l.ATTN_USED_DKV2
+                   else ("attn_bwd_dkv_kernel<head split>" if used & _l.ATTN_USED_HEAD_SPLIT else "attn_bwd_dkv_kernel"),
+            "batches_with_a_work_plan": f"{n_plans} of {len(batches)}"}
         if f_tok:
             out["mfma_roofline_frac_step"] = value * f_tok / (world * MFMA_PEAK_TFLOPS * 1e12)
             out["gflop_per_token"] = f_tok / 1e9

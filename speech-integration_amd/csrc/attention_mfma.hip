@@ -621,7 +621,8 @@ __global__ __launch_bounds__(64 * ANW, ANW == 8 ? 1 : 2) void attn_bwd_dq_kernel
 
 // =====================================================================================================================
 // backward: dQ — round 4: one wave per SIMD, hand-placed software pipeline, persistent workgroups
-// (plain causal rows, 4 query heads per kv head, S a multiple of 512)
+// (4 query heads per kv head; plain causal rows: S a multiple of 128, i.e. of 64 x 2, 4 or 8 query blocks per workgroup — the host takes the
+//  largest count that divides S / 64 and fills the chip; packed rows: round 5, from a work plan, see VARLEN below)
 // =====================================================================================================================
 // The recipe of attn_bwd_dkv2_kernel (further down: read its header first) applied to dQ.  An ITEM = 64 queries x the 4 query heads of a kv
 // head (wave w = head w), sweeping the 64-key tiles 0 .. its own; a UNIT = (32-key block kb, 32-query block qb) of a tile: 8 S^T / dP^T

@@ -92,6 +92,8 @@ class GradSync:
         self._wait_events: list = []
         self._bucket_events: list = []  # (bucket, bytes, issue event, completion event) while `timing`
         self._bucket_waits: list = []   # (bucket, event before / after the compute stream's wait for it) while `timing`
+        self._deferred_name: Optional[str] = None  # name of the bucket `finish(defer_last=True)` left in flight
+        self._max_timing_records = 4096  # `timing` without anybody calling bucket_report(): the event lists do not grow without bound
         self._stream_ordered_wait = bool(flat_grad.is_cuda and dist.is_available() and dist.is_initialized()
                                          and dist.get_backend(group) == "nccl")
         # token counts and the running loss travel on a communicator of their own: on the gradients' one they would queue behind
@@ -199,8 +201,12 @@ class GradSync:
             self._wait(self._deferred[0])
             end = self._mark(mark)
             if end is not None:
-                self._bucket_waits.append((getattr(self, "_deferred_name", "?") + " (deferred)", mark, end))
+                self._bucket_waits.append(((self._deferred_name or "?") + " (deferred)", mark, end))
             self._deferred = None
+            self._deferred_name = None
+        for rec in (self._bucket_events, self._bucket_waits, self._wait_events):  # a long timed run that never reads its report
+            if len(rec) > self._max_timing_records:
+                del rec[: len(rec) - self._max_timing_records]
 
     def _mark(self, start=None):
         """Timing events on the compute stream around a wait (only when ``timing``): the gap between them is the time the stream
