@@ -403,14 +403,32 @@ class HipLlamaDecoder(nn.Module):
     # SSI_SPLITK_NT=0 (A/B runs): keep the k-contiguous / data-gradient GEMMs unsplit whatever their output grid
     split_small_grids = os.environ.get("SSI_SPLITK_NT", "1") != "0"
 
+    # SSI_TAIL_SPLIT=0 (A/B runs): a ragged grid is K-split as a whole (the round-4 form) instead of in its last partial round only
+    split_tail_only = os.environ.get("SSI_TAIL_SPLIT", "1") != "0"
+
     def _gemm(self, layout: int, a: Tensor, b: Tensor, c: Tensor, residual: Optional[Tensor] = None) -> None:
         """``ops.gemm`` for the forward projections and the data gradients, with K split where the 256 x 256 output grid leaves CUs idle:
         at the reference's default micro-batches (``conf/data/_sft_base.yaml:21``: 2 x 2048 = 4096 rows) W_o, W2 and the data gradients of
         the N = 2048 projections have 128 tiles for 256 CUs, and a ragged packed length fills its last round badly.  ``ops.splitk_choice``
-        weighs the halved rounds against the fp32 partial tiles' traffic (K = 2048: a draw; K = 8192 / 16 384: 1.6-1.8 x)."""
+        weighs the halved rounds against the fp32 partial tiles' traffic (K = 2048: a draw; K = 8192 / 16 384: 1.6-1.8 x).
+
+        Round 5: a grid of MORE than one round (a right-padded batch after the unpadding: T' = 11 520 rows give the N = 2048 projections 360
+        tiles = 1.4 rounds) is split in its last, partial round only: the m-tile rows that fill whole rounds run unsplit, the rows behind
+        them as a second launch with its own K split — the same time on the matrix cores as the split of the whole grid (1.5 tile times
+        either way at 1.4 rounds), but fp32 partial tiles and their reduction pass for 104 tiles instead of 360."""
         M, N = c.shape
         K = a.shape[1]
-        splits = ops.splitk_choice(M, N, K) if (self.split_small_grids and self.dtype == torch.bfloat16 and self._mfma_shapes()) else 1
+        mfma = self.split_small_grids and self.dtype == torch.bfloat16 and self._mfma_shapes() and M % 256 == 0 and N % 256 == 0
+        if mfma and self.split_tail_only and layout in (GEMM_NT, GEMM_NN):
+            tm, tn = M // 256, N // 256
+            rounds = (tm * tn) // 256
+            m_main = (rounds * 256) // tn  # m-tile rows that fill whole rounds of the 256 CUs
+            if rounds >= 1 and 0 < m_main < tm and (tm - m_main) * tn <= 192:
+                rows = m_main * 256
+                ops.gemm(layout, a[:rows], b, c[:rows], residual=None if residual is None else residual[:rows])
+                self._gemm(layout, a[rows:], b, c[rows:], None if residual is None else residual[rows:])  # (fewer than 256 tiles: split as a whole)
+                return
+        splits = ops.splitk_choice(M, N, K) if mfma else 1
         if splits > 1:
             wsk = self._arena.get("ws.splitk.nt", (splits * M * N,), torch.float32)
             ops.gemm_splitk(layout, a, b, c, splits, wsk, residual=residual)

@@ -328,17 +328,24 @@ def test_full_width_model_on_ragged_padded_micro_batches_matches_the_cpu_oracle(
     # sums inside the attention kernels and the bf16 rounding behind them.
     from ssi.data import loss_inputs, unpad_batch
     grads, losses = {}, {}
-    for how in ("padded", "unpadded"):
+    # Round 5: a third time with the work plan of the attention backward the prefetch thread builds beside the packed copy (ssi/attn_plan.py):
+    # the packed rows then run the pipelined dQ / dK-dV kernels (asserted), document-aware forms.
+    from ssi import _lib, ops
+    to_dev = lambda v: v.to(DEV) if torch.is_tensor(v) else (v.to_device(DEV) if getattr(v, "is_attn_plan", False) else v)  # noqa: E731
+    for how in ("padded", "unpadded", "unpadded, work plan"):
         model.zero_grad(set_to_none=True)
         losses[how] = []
         for b, want in zip(batches, want_loss):
             n = int((b["labels"] != -100).sum())
-            hb = b if how == "padded" else unpad_batch(b, pad_id=pad_id, padded_len=model.padded_seq_len)
-            assert ("packed_tokens" in hb) == (how == "unpadded")
-            if how == "unpadded":
+            plan_fn = (lambda ip: model.build_attn_plan(ip, force=True)) if how.endswith("plan") else None   # (forced: a handful of rows is not what the plan is for)
+            hb = b if how == "padded" else unpad_batch(b, pad_id=pad_id, padded_len=model.padded_seq_len, plan_fn=plan_fn)
+            assert ("packed_tokens" in hb) == (how != "padded") and ("packed_attn_plan" in hb) == how.endswith("plan")
+            if how != "padded":
                 assert hb["packed_tokens"].shape[1] < b["tokens"].shape[0] * model.padded_seq_len(*b["tokens"].shape)
-            got = compute_loss(loss_inputs({k: v.to(DEV) for k, v in hb.items()}), model, CEWithChunkedOutputLoss())
+            got = compute_loss(loss_inputs({k: to_dev(v) for k, v in hb.items()}), model, CEWithChunkedOutputLoss())
             (got * n).backward()
+            want_bits = (_lib.ATTN_USED_DQ2 | _lib.ATTN_USED_DKV2 | _lib.ATTN_USED_PLAN) if how.endswith("plan") else 0
+            assert ops.attn_last_dispatch() & _lib.ATTN_USED_PLAN == want_bits & _lib.ATTN_USED_PLAN and ops.attn_last_dispatch() & want_bits == want_bits
             rel = abs(got.item() - want) / abs(want)
             print(f"[ragged full-width, {how}] B x S = {tuple(b['tokens'].shape)}: loss {got.item():.6f} vs oracle {want:.6f} (rel {rel:.2e})")
             assert rel <= 1e-2
@@ -358,13 +365,15 @@ def test_full_width_model_on_ragged_padded_micro_batches_matches_the_cpu_oracle(
         # rounding): the two losses sit 6e-6 .. 9e-5 from the fp32 oracle, on either side of it.  In fp32 the transform is exact to 1e-6
         # (tests/test_unpad.py, on the CPU oracle).
         assert abs(a - b_) <= 1e-4 * abs(a), (a, b_)
-    worst, worst_key = 0.0, None
-    for k in grads["padded"]:
-        err = float((grads["padded"][k] - grads["unpadded"][k]).norm() / grads["padded"][k].norm())
-        if err > worst:
-            worst, worst_key = err, k
-    print(f"[ragged full-width] padded vs unpadded: losses {losses}, worst relative gradient difference {worst:.2e} ({worst_key})")
-    assert worst <= 1e-2, (worst_key, worst)
+    assert losses["unpadded"] == losses["unpadded, work plan"]   # the plan is a matter of the backward
+    for other in ("unpadded", "unpadded, work plan"):
+        worst, worst_key = 0.0, None
+        for k in grads["padded"]:
+            err = float((grads["padded"][k] - grads[other][k]).norm() / grads["padded"][k].norm())
+            if err > worst:
+                worst, worst_key = err, k
+        print(f"[ragged full-width] padded vs {other}: losses {losses}, worst relative gradient difference {worst:.2e} ({worst_key})")
+        assert worst <= 1e-2, (worst_key, worst)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -451,6 +460,70 @@ def test_gemm_at_the_training_step_shapes_is_exact_on_integers(what, layout, M, 
     finally:
         ops.set_impl(prev)
         del a, b, ref, exact, c
+        torch.cuda.empty_cache()
+
+
+TAIL_SHAPES = [
+    # (what, layout, M, N, K): ragged row counts of an unpadded batch — more than one round of the 256 CUs, the last one partial
+    ("W_o forward at T'=11520 (360 tiles: 256 + 104 split)", 0, 11520, 2048, 2048),
+    ("W2 forward at T'=11520", 0, 11520, 2048, 8192),
+    ("gate-up data gradient at T'=11520", 1, 11520, 2048, 16384),
+    ("QKV data gradient at T'=9984 (312 tiles: 256 + 56 split)", 1, 9984, 2048, 3072),
+    ("W_o forward at T'=16640 (520 tiles: 512 + 8 split)", 0, 16640, 2048, 2048),
+    ("W_o forward at T'=13824 (432 tiles: 256 + 176 unsplit tail)", 0, 13824, 2048, 2048),
+]
+
+
+@pytest.mark.parametrize("what,layout,M,N,K", TAIL_SHAPES, ids=[s[0] for s in TAIL_SHAPES])
+def test_gemm_with_the_last_partial_round_split_is_exact_on_integers(what, layout, M, N, K):
+    """Round 5: ``HipLlamaDecoder._gemm`` on a grid of more than one round — whole rounds unsplit, the rows of the last partial round as a second
+    launch with its own K split — exact on sparse integers, with and without residual, and equal to the whole-grid forms bit for bit on such
+    data; the launches are counted (the split must actually happen where this test says it does)."""
+    from ssi import _lib, ops
+    from ssi.model import HipLlamaDecoder
+    cfg = _full_config(5000)
+    cfg.num_layers = 1
+    model = HipLlamaDecoder(**cfg.parameters, dtype=torch.bfloat16, device=DEV, rope_cache_len=256)
+    assert model._mfma_shapes() and model.split_tail_only and model.split_small_grids
+    p = min(0.5, math.sqrt(4096.0 / K))
+    a = _sparse_ints((M, K), p, 301)
+    b = _sparse_ints((N, K) if layout == 0 else (K, N), p, 302)
+    ref = (a.float() @ b.float().t()) if layout == 0 else (a.float() @ b.float())
+    exact = ref.abs() <= 256
+    assert float(exact.float().mean()) > 0.99
+    res = torch.randint(-2, 3, (M, N), device=DEV, generator=torch.Generator(device=DEV).manual_seed(303)).to(torch.bfloat16)
+    calls = []
+    real_gemm, real_split = ops.gemm, ops.gemm_splitk
+    ops.gemm = lambda layout_, a_, b_, c_, **kw: (calls.append(("gemm", c_.shape[0])), real_gemm(layout_, a_, b_, c_, **kw))[1]
+    ops.gemm_splitk = lambda layout_, a_, b_, c_, splits, ws, **kw: (calls.append(("splitk", c_.shape[0], splits)), real_split(layout_, a_, b_, c_, splits, ws, **kw))[1]
+    prev = ops.set_impl(_lib.IMPL_MFMA)
+    try:
+        out = {}
+        for tail_only in (True, False):
+            model.split_tail_only = tail_only
+            for r in (None, res):
+                c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+                calls.clear()
+                model._gemm(layout, a, b, c, residual=r)
+                out[tail_only, r is not None] = (c, list(calls))
+        tm, tn = M // 256, N // 256
+        m_main = ((tm * tn) // 256 * 256) // tn
+        got_calls = out[True, False][1]
+        assert got_calls[0] == ("gemm", m_main * 256), got_calls
+        tail = (tm - m_main) * tn
+        assert len(got_calls) == 2 and got_calls[1][1] == M - m_main * 256 and (got_calls[1][0] == "splitk") == (tail <= 128), got_calls
+        for r in (False, True):
+            want = ref.bfloat16().float() + (res.float() if r else 0.0)
+            ok = exact & (want == want.bfloat16().float())
+            assert float(ok.float().mean()) > 0.5
+            c = out[True, r][0]
+            assert bool(torch.isfinite(c.float()).all())
+            assert bool(((c.float() == want) | ~ok).all()), f"{what}: not exact (residual {r})"
+            assert torch.equal(c, out[False, r][0]), f"{what}: tail-split and whole-grid forms differ on exact data"
+    finally:
+        ops.set_impl(prev)
+        ops.gemm, ops.gemm_splitk = real_gemm, real_split
+        del model, a, b, ref, exact
         torch.cuda.empty_cache()
 
 

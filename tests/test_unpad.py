@@ -102,3 +102,55 @@ def test_prefetcher_applies_the_transform_in_its_thread():
     seen = list(DevicePrefetcher(batches, "cpu", depth=2, transform=lambda x: unpad_batch(x, pad_id=PAD, multiple=16)))
     assert len(seen) == 3 and all("packed_tokens" in x and x["packed_tokens"].shape == (1, 32) for x in seen)
     assert all(torch.equal(x["tokens"], y["tokens"]) for x, y in zip(seen, batches))
+
+
+def test_the_work_plan_of_the_attention_backward_travels_with_the_packed_copy():
+    """``plan_fn`` (the model's ``build_attn_plan``) is called with the HOST input_pos of the packed copy; its plan rides under
+    ``packed_attn_plan`` and reaches ``compute_loss`` as ``attn_plan``; a batch that arrives packed gains its plan too; nothing is attached
+    where the function declines.  The plan itself is built by the library on the host (no GPU needed)."""
+    from ssi import attn_plan
+    seen = []
+
+    def plan_fn(input_pos):
+        seen.append(input_pos.clone())
+        return attn_plan.plan_from_input_pos(input_pos, 8, 2, force=True)
+
+    b = _ragged(4, 300, [300, 170, 60, 290], prompt=3)
+    out = unpad_batch(b, pad_id=PAD, multiple=256, plan_fn=plan_fn)
+    plan = out["packed_attn_plan"]
+    assert torch.equal(seen[0], out["packed_input_pos"]) and plan.matches(1, 1024, 8, 2) and plan.dev is None
+    li = loss_inputs(out)
+    assert li["attn_plan"] is plan and set(li) == {"tokens", "labels", "input_pos", "attn_plan"}
+    # the documents of the plan are the rows (and the tile tail): every position belongs to exactly one item of either kind
+    docs = attn_plan.documents_from_input_pos(out["packed_input_pos"])
+    assert docs[1].tolist() == [0, 300, 470, 530, 820] and docs[2].tolist() == [300, 470, 530, 820, 1024]
+    cover_k, cover_q = torch.zeros(1024, dtype=torch.int32), torch.zeros(1024, dtype=torch.int32)
+    for _, k0, d0, d1 in plan.dkv_items():
+        assert k0 % 32 == 0
+        cover_k[max(k0, d0):min(k0 + 256, d1)] += 1
+    loads = []
+    for grp in plan.dq_groups():
+        assert grp == sorted(grp, key=lambda it: -(it[1] // 64 - it[2] // 64)), "a group's items come heaviest first"
+        loads.append(sum(it[1] // 64 - it[2] // 64 + 1 for it in grp))
+        for _, q0, d0, d1 in grp:
+            assert q0 % 64 == 0
+            cover_q[max(q0, d0):min(q0 + 64, d1)] += 1
+    assert bool((cover_k == 1).all()) and bool((cover_q == 1).all())
+    works = [d1 // 32 + (d1 % 32 > 0) - k0 // 32 for _, k0, d0, d1 in plan.dkv_items()]
+    assert works == sorted(works, reverse=True), "dK/dV items come heaviest first"
+    # a batch that arrives packed
+    packed = {**_ragged(1, 256, [256]), "input_pos": torch.cat([torch.arange(100), torch.arange(156)])[None]}
+    got = unpad_batch(packed, pad_id=PAD, multiple=256, plan_fn=plan_fn)
+    assert got["attn_plan"].matches(1, 256, 8, 2) and "packed_tokens" not in got
+    # positions that are not document-relative: no plan (the kernels derive the RoPE position from the document start)
+    odd = {**_ragged(1, 256, [256]), "input_pos": (torch.arange(256) + 5)[None]}
+    assert attn_plan.documents_from_input_pos(odd["input_pos"]) is None and "attn_plan" not in unpad_batch(odd, pad_id=PAD, plan_fn=plan_fn)
+    assert "packed_attn_plan" not in unpad_batch(b, pad_id=PAD, multiple=256, plan_fn=lambda ip: None)
+
+
+def test_prefetcher_hands_the_plan_through():
+    from ssi import attn_plan
+    batches = [_ragged(2, 300, [200, 90], seed=i) for i in range(2)]
+    tf = lambda x: unpad_batch(x, pad_id=PAD, multiple=256, plan_fn=lambda ip: attn_plan.plan_from_input_pos(ip, 4, 1, force=True))  # noqa: E731
+    seen = list(DevicePrefetcher(batches, "cpu", depth=2, transform=tf))
+    assert all(x["packed_attn_plan"].matches(1, 512, 4, 1) for x in seen)
