@@ -15,6 +15,7 @@
 // group).  No atomics anywhere: dQ gets its own pass (recomputing S and dP) so every output has exactly one writer and
 // results are bitwise reproducible.
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <atomic>
 #include <vector>
@@ -1452,16 +1453,19 @@ constexpr int DKV2_MAX_STEPS = 2048;  // tiles per workgroup = (S / 32) * rep at
 // 32 —, document [dstart, dend)) = the up to 256 keys k0 .. k0 + 255 of ONE document, items sorted by work, heaviest first; a workgroup =
 // (item, kv head).  Because an item never leaves its document, everything that made packed rows expensive in the 128-key kernel is uniform
 // here: the query tiles are those from k0 to the END OF THE DOCUMENT (tiles of other documents are skipped, not masked — they are simply
-// not in the tile table), the masked tiles are the 8 on the diagonal plus the document's last tile when the document does not end on a
-// 32-row boundary (queries >= dend belong to the next document), and the mask is  key <= query < dend  with dend a scalar.  Lanes whose key
-// lies outside [dstart, dend) — the head of the first item of a document that does not start on a 32-row boundary, the tail of its last
-// item — compute on clamped rows and store nothing (key = lane: whatever they accumulate stays in their own columns).
+// not in the tile table), and the masked tiles are the 8 on the diagonal, with the plain rows' mask  key <= query.  The document's last tile,
+// when the document does not end on a 32-row boundary, holds queries of the NEXT document: they are taken out by their row constant, not by
+// a mask — the lanes that fetch lse[q] for q >= dend fetch 1e30 instead (one word of the plan's header), so P = exp2((S - lse) log2 e) = 0
+// exactly and dS = P (dP - delta) = 0 for those rows at no cost in the loops (first build: a second condition in the mask, 1.5 compares and
+// a scalar instruction per element more in every masked tile).  Lanes whose key lies outside [dstart, dend) — the head of the first item
+// of a document that does not start on a 32-row boundary, the tail of its last item — compute on clamped rows and store nothing (key = lane:
+// whatever they accumulate stays in their own columns).
 template <bool VARLEN>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, const float* __restrict__ rope,
                                                                const int32_t* __restrict__ positions, int S, int H, int KV,
-                                                               const int4* __restrict__ items) {
+                                                               const int4* __restrict__ items, const float* __restrict__ lse_beyond) {
     constexpr int SB = DKV2_SB, RING = DKV2_RING;
     __shared__ __attribute__((aligned(16))) char smem[RING * SB + DKV2_MAX_STEPS * 4];  // ring of [Q tile 4 KiB | dO tile 4 KiB | lse 128 B | delta 128 B], tile table
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1521,10 +1525,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
     // arch VGPRs and copies them into the accumulation registers in front of every MFMA (1 500 v_accvgpr moves and 400 scratch accesses in
     // the loop of the first build).  The order of the sums over the tiles differs from attn_bwd_dkv_kernel's, so the two kernels agree to
     // rounding, not bit for bit; each is reproducible run to run.
-    // masked tiles per head: the group's diagonal (8 tiles; fewer when the document ends inside it), and with VARLEN the document's last tile
-    // when it is not on the diagonal and holds queries of the next document
-    const int n_diag = VARLEN ? (per_head < 8 ? per_head : 8) : 8;
-    const int n_edge = VARLEN ? n_diag + ((per_head > 8 && (dend & 31)) ? 1 : 0) : 8;
+    // masked tiles per head: the group's diagonal (8 tiles; with VARLEN fewer when the document ends inside it)
+    const int n_edge = VARLEN ? (per_head < 8 ? per_head : 8) : 8;
     const int n_masked = n_edge * rep;          // tiles of the first loop; a multiple of 4, like n_steps
     // tile i of the sequence -> (head << 16) | tile of the head, looked up in a table in LDS behind the ring (built once per workgroup): the
     // requests run 6-7 tiles ahead of the products and cross heads and loops at other times, and a cursor kept in scalar registers by selects
@@ -1532,9 +1534,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
     int* seq_tab = reinterpret_cast<int*>(smem + RING * SB);
     for (int i = tid; i < n_steps; i += 256) {
         const int j = i < n_masked ? i : i - n_masked, len = i < n_masked ? n_edge : per_head - n_edge;
-        int tile = (i < n_masked ? 0 : n_diag) + j % len;
-        if (VARLEN && i < n_masked && j % len >= n_diag) tile = per_head - 1;  // the document's last tile
-        seq_tab[i] = ((j / len) << 16) | tile;
+        seq_tab[i] = ((j / len) << 16) | ((i < n_masked ? 0 : n_edge) + j % len);
     }
     const int irow = wave * 8 + (lane >> 3), ichunk = (lane & 7) ^ swz<SWZ_DUAL>(wave * 8 + (lane >> 3));
     const u32x4 rs_q = buffer_rsrc(qkv + row0 * ld + (int64_t)kvh * rep * HD);
@@ -1561,6 +1561,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
         else if (part == 1) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff_do), "s"(rs_do), "s"((unsigned)(qrow * (int)ldo * 2 + hoff)) : "memory");
         else {
             const float* src = rc_base + ((w >> 16) * S + qrow);
+            if constexpr (VARLEN) {  // queries of the next document (the document's last tile): lse = 1e30 -> P = 0, dS = 0
+                if (lane < 32 && qrow + lane >= dend) src = lse_beyond;
+            }
             asm volatile("global_load_lds_dword %0, off" ::"v"(src) : "memory");
         }
     };
@@ -1634,7 +1637,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
             float p = __builtin_amdgcn_exp2f(sacc[kb][g] * -LOG2E);
             if (EDGE) {
                 const int q = q0 + rowmap(g, h);
-                if (VARLEN ? (kg[kb] > q || q >= dend) : kg[kb] > q) p = 0.f;  // keys beyond the query (queries beyond the document) contribute nothing
+                if (kg[kb] > q) p = 0.f;  // keys beyond the query contribute nothing
             }
             pv[g] = p;
         }
@@ -1781,7 +1784,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
         int q0[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            q0[i] = (qb_first + (VARLEN && cur_qt >= n_diag ? per_head - 1 : cur_qt)) * 32;
+            q0[i] = (qb_first + cur_qt) * 32;
             cur_qt = cur_qt + 1 == n_edge ? 0 : cur_qt + 1;
         }
         using P0 = std::integral_constant<int, 0>;
@@ -1951,7 +1954,7 @@ int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, const 
 // Layout of a plan (int32 words; built on the HOST by ssi_attn_plan_build, copied to the device by the caller; the first SSI_ATTN_PLAN_HEADER
 // words are also what the launch needs on the host):
 //   [0] magic  [1] n_dkv_items  [2] word offset of the dK/dV items  [3] n_dq_groups  [4] word offset of the dQ groups  [5] words per dQ group
-//   [6] batch  [7] seq  [8] n_heads  [9] n_kv  [10] total words  [11] n_docs  [12 ..15] reserved
+//   [6] batch  [7] seq  [8] n_heads  [9] n_kv  [10] total words  [11] n_docs  [12] 1e30f (read by attn_bwd_dkv2_kernel<true>)  [13 ..15] reserved
 //   dK/dV items: n_dkv_items x {b, k0, dstart, dend}, heaviest first (see attn_bwd_dkv2_kernel<true>)
 //   dQ groups  : n_dq_groups x [{n_items, load, 0, 0}, cap x {b, q0, dstart, dend}] (see attn_bwd_dq2_kernel<0, true>)
 constexpr int32_t PLAN_MAGIC = 0x53534950;  // "SSIP"
@@ -2025,6 +2028,7 @@ extern "C" int64_t ssi_attn_plan_build(const int32_t* host_doc_row, const int32_
     for (int i = 0; i < SSI_ATTN_PLAN_HEADER; ++i) hd[i] = 0;
     hd[0] = PLAN_MAGIC, hd[1] = (int32_t)dkv.size(), hd[2] = (int32_t)dkv_off, hd[3] = n_groups, hd[4] = (int32_t)dq_off, hd[5] = (int32_t)gstride;
     hd[6] = (int32_t)batch, hd[7] = (int32_t)seq, hd[8] = n_heads, hd[9] = n_kv, hd[10] = (int32_t)words, hd[11] = (int32_t)n_docs;
+    { const float big = 1e30f; memcpy(&hd[12], &big, sizeof(float)); }  // the "log-sum-exp" of a query that belongs to another document: P = 0
     int32_t* w = host_plan + dkv_off;
     for (const It& it : dkv) { w[0] = it.b, w[1] = it.r0, w[2] = it.ds, w[3] = it.de; w += 4; }
     for (int g = 0; g < n_groups; ++g) {
@@ -2107,11 +2111,13 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
     const bool v2 = !doc_end && seq % 256 == 0 && rep % 4 == 0 && (seq / 32) * rep <= DKV2_MAX_STEPS && balanced && sel != SSI_ATTN_MODE_OLD;
     if (ph && sel != SSI_ATTN_MODE_OLD) {
         hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, dim3((unsigned)(ph[1] * n_kv)), dim3(256), 0, st, (const bf16_t*)qkv, ld, (const bf16_t*)dout, lse,
-                           delta, (bf16_t*)dqkv, rope, positions, (int)seq, n_heads, n_kv, reinterpret_cast<const int4*>(plan_dev + ph[2]));
+                           delta, (bf16_t*)dqkv, rope, positions, (int)seq, n_heads, n_kv, reinterpret_cast<const int4*>(plan_dev + ph[2]),
+                           reinterpret_cast<const float*>(plan_dev + 12));
         used |= SSI_ATTN_USED_DKV2 | SSI_ATTN_USED_PLAN;
     } else if (v2) {
         hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, dim3((unsigned)(batch * n_kv * (seq / 256))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
-                           (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, rope, positions, (int)seq, n_heads, n_kv, (const int4*)nullptr);
+                           (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, rope, positions, (int)seq, n_heads, n_kv, (const int4*)nullptr,
+                           (const float*)nullptr);
         used |= SSI_ATTN_USED_DKV2;
     } else {
         // small launches: one workgroup per query head + a reduction, when the caller brought the workspace (mode NO_HEAD_SPLIT: never)
