@@ -170,12 +170,16 @@ int ssi_attn_last_dispatch(void);
  *   host_doc_row / _start / _end: n_docs documents as (row b, first position, one past the last position) — they must tile every row.
  *   flags: SSI_ATTN_PLAN_FORCE = build the plan even where the round-1..3 kernels are expected to be faster (tests).
  *   ssi_attn_plan_words: upper bound of a plan's size in int32 words.  ssi_attn_plan_build: words written (> 0); 0 = the pipelined kernels
- *   do not take this batch (other than 4 query heads per kv head, a document longer than 16 384 tokens, mostly tiny documents, a few long
- *   documents and nothing else) — pass no plan then; < 0 = bad arguments.  The first SSI_ATTN_PLAN_HEADER words are the header the launch
+ *   do not take this batch (other than 4 query heads per kv head, a document longer than 16 384 tokens, mostly tiny documents) — pass no
+ *   plan then; < 0 = bad arguments.  The first SSI_ATTN_PLAN_HEADER words are the header the launch
  *   reads on the host.  RoPE positions are taken to be (position - document start): build no plan for batches whose input_pos does
  *   anything else. */
-enum { SSI_ATTN_PLAN_HEADER = 16, SSI_ATTN_PLAN_FORCE = 1 };
+enum { SSI_ATTN_PLAN_HEADER = 16, SSI_ATTN_PLAN_FORCE = 1, SSI_ATTN_PLAN_SPLIT_ALL = 2 /* tests: every dK/dV chunk split over the query heads */ };
 int64_t ssi_attn_plan_words(int64_t batch, int64_t seq, int64_t n_docs);
+/* dK/dV chunks whose work exceeds the chip's share per compute unit (long documents) are split over the query heads: fp32 partial sums in
+ * the caller's workspace, added by a reduction pass over those chunks only.  ssi_attn_plan_workspace_bytes: what ssi_attn_varlen_bwd_plan needs
+ * in `workspace` for this plan (0: nothing was split; -1: not a plan header). */
+int64_t ssi_attn_plan_workspace_bytes(const int32_t* host_plan_header);
 int64_t ssi_attn_plan_build(const int32_t* host_doc_row, const int32_t* host_doc_start, const int32_t* host_doc_end, int64_t n_docs,
                             int64_t batch, int64_t seq, int n_heads, int n_kv, int flags, int32_t* host_plan, int64_t plan_words);
 /* ssi_attn_varlen_bwd_ws + a plan: plan = the plan in DEVICE memory, host_plan_header = its first SSI_ATTN_PLAN_HEADER words on the host

@@ -1465,17 +1465,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, const float* __restrict__ rope,
                                                                const int32_t* __restrict__ positions, int S, int H, int KV,
-                                                               const int4* __restrict__ items, const float* __restrict__ lse_beyond) {
+                                                               const int4* __restrict__ items, const float* __restrict__ lse_beyond,
+                                                               float* __restrict__ partial) {
     constexpr int SB = DKV2_SB, RING = DKV2_RING;
     __shared__ __attribute__((aligned(16))) char smem[RING * SB + DKV2_MAX_STEPS * 4];  // ring of [Q tile 4 KiB | dO tile 4 KiB | lse 128 B | delta 128 B], tile table
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rep = H / KV;
+    const int rep_all = H / KV;
+    // query heads this workgroup sweeps: all of the kv head's, or (VARLEN) the item's share of them — a heavy item of the plan is split over
+    // the query heads (2 or 4 workgroups whose fp32 sums meet in attn_dkv_plan_reduce_kernel), so that a launch is not as long as its longest document
+    int rep = rep_all, head0 = 0, pslot = -1;
     int kvh, b, k0, dstart = 0, dend = S;
     if constexpr (VARLEN) {  // workgroup -> (item, kv head): consecutive workgroups = the kv heads of one item, i.e. (KV = 8) one per XCD
         const int id = (int)blockIdx.x;
         kvh = id % KV;
-        const int4 it = items[id / KV];  // (uniform address: scalar loads)
+        const int4 it = items[2 * (id / KV)], ih = items[2 * (id / KV) + 1];  // (uniform address: scalar loads)
         b = it.x, k0 = it.y, dstart = it.z, dend = it.w;
+        head0 = ih.x, rep = ih.y, pslot = ih.z;
     } else {
         const int ngrp = S / 256;
         int kgrp, pair_;  // low key groups (most work) are dispatched first
@@ -1517,7 +1522,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
 
     const int qb_first = k0 / 32;                                        // first 32-query tile that sees any key of the group
     const int per_head = (VARLEN ? (dend + 31) / 32 : S / 32) - qb_first;  // tiles per query head (plain rows: >= 8)
-    const int n_steps = per_head * rep;                                  // a multiple of 4: the host takes this kernel for rep % 4 == 0 only
+    // tiles of the two loops, each a multiple of 4 (a trip): plain rows come with rep % 4 == 0; an item of the plan that sweeps 1 or 2 heads
+    // is padded with DUMMY tiles — any tile's Q / dO under lse = 1e30 for all its rows, i.e. P = 0, dS = 0: exact zeros added
 
     // ---- LDS-DMA requests: as in attn_bwd_dkv_kernel, three per tile and wave, issued part by part ----------------------------------------
     // Tile order: the MASKED tiles of every head first (the 8 tiles on the group's diagonal), then the rest of every head.  Two plain loops, one per form of the exponentials — not an if / else per period and not two inner loops taking turns:
@@ -1527,20 +1533,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
     // rounding, not bit for bit; each is reproducible run to run.
     // masked tiles per head: the group's diagonal (8 tiles; with VARLEN fewer when the document ends inside it)
     const int n_edge = VARLEN ? (per_head < 8 ? per_head : 8) : 8;
-    const int n_masked = n_edge * rep;          // tiles of the first loop; a multiple of 4, like n_steps
+    const int n_masked_real = n_edge * rep, n_rest_real = (per_head - n_edge) * rep;
+    const int n_masked = VARLEN ? (n_masked_real + 3) & ~3 : n_masked_real;          // tiles of the first loop
+    const int n_steps = n_masked + (VARLEN ? (n_rest_real + 3) & ~3 : n_rest_real);
     // tile i of the sequence -> (head << 16) | tile of the head, looked up in a table in LDS behind the ring (built once per workgroup): the
     // requests run 6-7 tiles ahead of the products and cross heads and loops at other times, and a cursor kept in scalar registers by selects
     // cost ~50 scalar instructions per trip, all in front of its first MFMA
     int* seq_tab = reinterpret_cast<int*>(smem + RING * SB);
     for (int i = tid; i < n_steps; i += 256) {
         const int j = i < n_masked ? i : i - n_masked, len = i < n_masked ? n_edge : per_head - n_edge;
-        seq_tab[i] = ((j / len) << 16) | ((i < n_masked ? 0 : n_edge) + j % len);
+        int w = 0x8000;  // dummy: tile 0 of the first head, bit 15 = "its rows see nothing"
+        if (!VARLEN || j < (i < n_masked ? n_masked_real : n_rest_real)) w = ((j / len) << 16) | ((i < n_masked ? 0 : n_edge) + j % len);
+        seq_tab[i] = w;
     }
     const int irow = wave * 8 + (lane >> 3), ichunk = (lane & 7) ^ swz<SWZ_DUAL>(wave * 8 + (lane >> 3));
-    const u32x4 rs_q = buffer_rsrc(qkv + row0 * ld + (int64_t)kvh * rep * HD);
-    const u32x4 rs_do = buffer_rsrc(dout + row0 * ldo + (int64_t)kvh * rep * HD);
+    const u32x4 rs_q = buffer_rsrc(qkv + row0 * ld + (int64_t)(kvh * rep_all + head0) * HD);
+    const u32x4 rs_do = buffer_rsrc(dout + row0 * ldo + (int64_t)(kvh * rep_all + head0) * HD);
     const unsigned voff_q = (unsigned)((irow * ld + ichunk * 8) * 2), voff_do = (unsigned)((irow * ldo + ichunk * 8) * 2);
-    const float* rc_base = (lane < 32 ? lse : delta) + ((int64_t)b * H + kvh * rep) * S + (lane & 31);
+    const float* rc_base = (lane < 32 ? lse : delta) + ((int64_t)b * H + kvh * rep_all + head0) * S + (lane & 31);
     const unsigned lds_piece = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)smem + (unsigned)wave * 1024u);
     const unsigned lds_rc = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_c*)smem + 8192u);
     // Requests are issued for EVERY ring position, also behind the last tile (the last tile again; the bytes go to a slot nobody reads): the
@@ -1556,13 +1566,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
         asm volatile("s_mov_b32 m0, %0" ::"s"(dst) : "memory");
     };
     auto issue_go = [&](int w, int part) __attribute__((always_inline)) {  // w = table word of the tile
-        const int qrow = (qb_first + (w & 0xffff)) * 32, hoff = (w >> 16) * (HD * 2);
+        const int qrow = (qb_first + (w & 0x7fff)) * 32, hoff = (w >> 16) * (HD * 2);
         if (part == 0) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff_q), "s"(rs_q), "s"((unsigned)(qrow * (int)ld * 2 + hoff)) : "memory");
         else if (part == 1) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff_do), "s"(rs_do), "s"((unsigned)(qrow * (int)ldo * 2 + hoff)) : "memory");
         else {
             const float* src = rc_base + ((w >> 16) * S + qrow);
             if constexpr (VARLEN) {  // queries of the next document (the document's last tile): lse = 1e30 -> P = 0, dS = 0
-                if (lane < 32 && qrow + lane >= dend) src = lse_beyond;
+                const int seen_until = (w & 0x8000) ? 0 : dend;  // (a scalar select, no branch: a trip stays one basic block)
+                if (lane < 32 && qrow + lane >= seen_until) src = lse_beyond;
             }
             asm volatile("global_load_lds_dword %0, off" ::"v"(src) : "memory");
         }
@@ -1815,6 +1826,25 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
     const unsigned long long st2_total = __builtin_readcyclecounter() - st2_begin;
 #endif
 
+    if constexpr (VARLEN) {
+        if (pslot >= 0) {  // an item split over the query heads: raw fp32 sums [slot][kv head][key of the item][dK 64 | dV 64]; scale, RoPE backward
+#pragma unroll             // and rounding happen after the heads are added (attn_dkv_plan_reduce_kernel)
+            for (int kb = 0; kb < 2; ++kb) {
+                float* prow = partial + (((int64_t)pslot * KV + kvh) * 256 + (kg[kb] - k0)) * 128;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 vk, vv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { vk[e] = dk[kb][db][4 * g + e]; vv[e] = dv[kb][db][4 * g + e]; }
+                        *reinterpret_cast<f32x4*>(prow + db * 32 + 8 * g + 4 * h) = vk;
+                        *reinterpret_cast<f32x4*>(prow + 64 + db * 32 + 8 * g + 4 * h) = vv;
+                    }
+            }
+            return;
+        }
+    }
     const float* tb0 = rope ? rope : nullptr;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -1894,6 +1924,38 @@ __global__ __launch_bounds__(256) void attn_dkv_head_reduce_kernel(const float* 
     *reinterpret_cast<bf16x4*>(dst) = o;
 }
 
+// The items of a plan that were split over the query heads: adds their slots' fp32 rows in slot order (fixed: reproducible), then the epilogue of
+// attn_bwd_dkv2_kernel.  red = {b, k0, dstart, dend}, {first slot, slots, 0, 0} per split 256-key chunk; one thread per (key, 4 columns).
+__global__ __launch_bounds__(256) void attn_dkv_plan_reduce_kernel(const float* __restrict__ partial, const int4* __restrict__ red, int KV,
+                                                                   bf16_t* __restrict__ dqkv, int64_t ld, int H, const float* __restrict__ rope,
+                                                                   const int32_t* __restrict__ positions, int S) {
+    const int chunk = (int)blockIdx.x / (KV * 32), kvh = ((int)blockIdx.x / 32) % KV;
+    const int4 it = red[2 * chunk], is = red[2 * chunk + 1];
+    const int i = ((int)blockIdx.x % 32) * 256 + (int)threadIdx.x;  // (key of the chunk, c4): dK columns 4 c4 .. (c4 < 16), dV columns 4 (c4 - 16) ..
+    const int key = i >> 5, c4 = i & 31, kg = it.y + key;
+    if (kg < it.z || kg >= it.w) return;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < is.y; ++sl) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (((int64_t)(is.x + sl) * KV + kvh) * 256 + key) * 128 + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum[e] += v[e];
+    }
+    const int64_t row = (int64_t)it.x * S + kg;
+    bf16x4 o;
+    bf16_t* dst;
+    if (c4 < 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(sum[e] * -0.125f);
+        if (rope) o = unrope4(o, rope + (int64_t)(positions ? positions[row] : kg) * HD, c4 * 4);
+        dst = dqkv + row * ld + (int64_t)H * HD + (int64_t)kvh * HD + c4 * 4;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)sum[e];
+        dst = dqkv + row * ld + (int64_t)(H + KV) * HD + (int64_t)kvh * HD + (c4 - 16) * 4;
+    }
+    *reinterpret_cast<bf16x4*>(dst) = o;
+}
+
 // Which backward kernels ssi_attn_bwd_mfma may take (ssi_set_attn_impl; process-global like ssi_set_impl).  The environment variables
 // SSI_ATTN_DQ / SSI_ATTN_DKV give the INITIAL values, read once under C++ static initialisation — never on the launch path.
 static int attn_env_mode(const char* name, int max_mode) {
@@ -1954,8 +2016,10 @@ int ssi_attn_fwd_mfma(const void* qkv, int64_t ld, void* out, float* lse, const 
 // Layout of a plan (int32 words; built on the HOST by ssi_attn_plan_build, copied to the device by the caller; the first SSI_ATTN_PLAN_HEADER
 // words are also what the launch needs on the host):
 //   [0] magic  [1] n_dkv_items  [2] word offset of the dK/dV items  [3] n_dq_groups  [4] word offset of the dQ groups  [5] words per dQ group
-//   [6] batch  [7] seq  [8] n_heads  [9] n_kv  [10] total words  [11] n_docs  [12] 1e30f (read by attn_bwd_dkv2_kernel<true>)  [13 ..15] reserved
-//   dK/dV items: n_dkv_items x {b, k0, dstart, dend}, heaviest first (see attn_bwd_dkv2_kernel<true>)
+//   [6] batch  [7] seq  [8] n_heads  [9] n_kv  [10] total words  [11] n_docs  [12] 1e30f (read by attn_bwd_dkv2_kernel<true>)
+//   [13] n_reduce  [14] word offset of the reduce list  [15] fp32 partial slots (workspace = slots x n_kv x 256 x 128 x 4 bytes)
+//   dK/dV items: n_dkv_items x [{b, k0, dstart, dend}, {first query head, query heads, partial slot or -1, 0}], heaviest first
+//   reduce list: n_reduce x [{b, k0, dstart, dend}, {first slot, slots, 0, 0}]: the 256-key chunks that were split over the query heads
 //   dQ groups  : n_dq_groups x [{n_items, load, 0, 0}, cap x {b, q0, dstart, dend}] (see attn_bwd_dq2_kernel<0, true>)
 constexpr int32_t PLAN_MAGIC = 0x53534950;  // "SSIP"
 static_assert(SSI_ATTN_PLAN_HEADER == 16, "plan header");
@@ -1963,7 +2027,7 @@ static_assert(SSI_ATTN_PLAN_HEADER == 16, "plan header");
 extern "C" int64_t ssi_attn_plan_words(int64_t batch, int64_t seq, int64_t n_docs) {
     if (batch <= 0 || seq <= 0 || n_docs <= 0) return 0;
     const int64_t dkv = batch * seq / 256 + 2 * n_docs, dq = batch * seq / 64 + 2 * n_docs;
-    return SSI_ATTN_PLAN_HEADER + 4 * dkv + 4 * (dq + 512 /* group headers */ + dq /* slack of the fixed group stride */);
+    return SSI_ATTN_PLAN_HEADER + 8 * 4 * dkv /* split 4 ways */ + 8 * dkv /* reduce list */ + 4 * (dq + 512 /* group headers */ + dq /* slack of the fixed group stride */);
 }
 
 // Returns the number of words written (> 0), 0 when the pipelined kernels do not take this batch (the caller then passes no plan and the
@@ -1974,7 +2038,7 @@ extern "C" int64_t ssi_attn_plan_build(const int32_t* host_doc_row, const int32_
     if (plan_words < ssi_attn_plan_words(batch, seq, n_docs)) return -1;
     const bool force = (flags & SSI_ATTN_PLAN_FORCE) != 0;
     if (n_heads != 4 * n_kv || seq % 128 != 0 || seq > (1 << 24)) return 0;  // the pipelined kernels: 4 query heads per kv head
-    struct It { int32_t b, r0, ds, de, work; };
+    struct It { int32_t b, r0, ds, de, work, head0 = 0, heads = 4, pslot = -1; };
     std::vector<It> dkv, dq;
     std::vector<int64_t> covered((size_t)batch, 0);
     int64_t keys = 0;
@@ -1985,8 +2049,8 @@ extern "C" int64_t ssi_attn_plan_build(const int32_t* host_doc_row, const int32_
         keys += de - ds;
         for (int32_t k0 = ds & ~31; k0 < de; k0 += 256) {
             const int per_head = (de + 31) / 32 - k0 / 32;
-            if (per_head * 4 > DKV2_MAX_STEPS) return 0;  // a document longer than the tile table
-            dkv.push_back({b, k0, ds, de, per_head});
+            if (per_head * 4 + 8 > DKV2_MAX_STEPS) return 0;  // a document longer than the tile table
+            dkv.push_back({b, k0, ds, de, per_head * 4});
         }
         for (int32_t q0 = ds & ~63; q0 < de; q0 += 64) dq.push_back({b, q0, ds, de, (q0 >> 6) - (ds >> 6) + 1});
     }
@@ -1994,17 +2058,34 @@ extern "C" int64_t ssi_attn_plan_build(const int32_t* host_doc_row, const int32_
         if (covered[(size_t)b] != seq) return -1;  // the documents must tile every row (overlaps are the caller's bug; gaps are caught here)
     // stable sorts by work, heaviest first (ties keep document order: reproducible plans)
     auto by_work = [](const It& x, const It& y) { return x.work > y.work; };
-    std::stable_sort(dkv.begin(), dkv.end(), by_work);
     std::stable_sort(dq.begin(), dq.end(), by_work);
+    // dK/dV is one workgroup per (item, kv head) and CU: a launch lasts at least as long as its heaviest item.  Items above the chip's share
+    // per CU are split over the query heads (2 x 2 or 4 x 1 heads; fp32 partial sums, added by a reduction pass over those chunks only)
+    int64_t total = 0;
+    for (const It& it : dkv) total += it.work;
+    const int64_t share = std::max<int64_t>(1, total * n_kv / 256), n_chunks = (int64_t)dkv.size();
+    const bool split_all = (flags & SSI_ATTN_PLAN_SPLIT_ALL) != 0;
+    std::vector<It> items, red;
+    int32_t n_slots = 0;
+    for (const It& it : dkv) {
+        int ways = 1;
+        if (split_all) ways = (it.r0 / 256) % 2 ? 2 : 4;
+        else if (it.work * 20 > share * 23 && it.work > 32) ways = it.work * 10 > share * 23 ? 4 : 2;
+        if (ways == 1) { items.push_back(it); continue; }
+        It r = it;
+        r.pslot = n_slots, r.heads = ways;  // (reduce entry: first slot, slots)
+        red.push_back(r);
+        for (int w = 0; w < ways; ++w) {
+            It part = it;
+            part.heads = 4 / ways, part.head0 = w * (4 / ways), part.pslot = n_slots++, part.work = it.work / ways;
+            items.push_back(part);
+        }
+    }
+    std::stable_sort(items.begin(), items.end(), by_work);
+    dkv.swap(items);
     if (!force) {
         // many short documents: an item has room for 256 keys (dK/dV) / 64 queries (dQ) whatever the document holds
-        if ((int64_t)dkv.size() * 256 > 2 * keys + 2048 || (int64_t)dq.size() * 64 > 2 * keys + 2048) return 0;
-        // dK/dV is one workgroup per (item, kv head) and CU: a launch lasts at least as long as its heaviest item.  Up to twice the chip's
-        // share per CU is accepted (the 128-key kernel this would fall back to suffers from the same long documents); beyond that — a few
-        // long documents and nothing else — its split over the query heads is the better tool
-        int64_t total = 0;
-        for (const It& it : dkv) total += it.work;
-        if ((int64_t)dkv[0].work * 256 > 2 * total * n_kv) return 0;
+        if (n_chunks * 256 > 2 * keys + 2048 || (int64_t)dq.size() * 64 > 2 * keys + 2048) return 0;
     }
     // dQ: groups of equal load for persistent workgroups, one round of the chip (256 workgroups over n_kv heads), longest processing time first
     const int fixed_cost = 6;  // an item's cost outside its tiles, in tiles (14 000 of ~2 400 cycles)
@@ -2021,7 +2102,7 @@ extern "C" int64_t ssi_attn_plan_build(const int32_t* host_doc_row, const int32_
     size_t cap = 0;
     for (const auto& g : groups) cap = std::max(cap, g.size());
     const int64_t gstride = 4 * (1 + (int64_t)cap);
-    const int64_t dkv_off = SSI_ATTN_PLAN_HEADER, dq_off = dkv_off + 4 * (int64_t)dkv.size();
+    const int64_t dkv_off = SSI_ATTN_PLAN_HEADER, red_off = dkv_off + 8 * (int64_t)dkv.size(), dq_off = red_off + 8 * (int64_t)red.size();
     const int64_t words = dq_off + gstride * n_groups;
     if (words > plan_words) return -1;
     int32_t* hd = host_plan;
@@ -2029,8 +2110,10 @@ extern "C" int64_t ssi_attn_plan_build(const int32_t* host_doc_row, const int32_
     hd[0] = PLAN_MAGIC, hd[1] = (int32_t)dkv.size(), hd[2] = (int32_t)dkv_off, hd[3] = n_groups, hd[4] = (int32_t)dq_off, hd[5] = (int32_t)gstride;
     hd[6] = (int32_t)batch, hd[7] = (int32_t)seq, hd[8] = n_heads, hd[9] = n_kv, hd[10] = (int32_t)words, hd[11] = (int32_t)n_docs;
     { const float big = 1e30f; memcpy(&hd[12], &big, sizeof(float)); }  // the "log-sum-exp" of a query that belongs to another document: P = 0
+    hd[13] = (int32_t)red.size(), hd[14] = (int32_t)red_off, hd[15] = n_slots;
     int32_t* w = host_plan + dkv_off;
-    for (const It& it : dkv) { w[0] = it.b, w[1] = it.r0, w[2] = it.ds, w[3] = it.de; w += 4; }
+    for (const It& it : dkv) { w[0] = it.b, w[1] = it.r0, w[2] = it.ds, w[3] = it.de, w[4] = it.head0, w[5] = it.heads, w[6] = it.pslot, w[7] = 0; w += 8; }
+    for (const It& it : red) { w[0] = it.b, w[1] = it.r0, w[2] = it.ds, w[3] = it.de, w[4] = it.pslot, w[5] = it.heads, w[6] = w[7] = 0; w += 8; }
     for (int g = 0; g < n_groups; ++g) {
         w = host_plan + dq_off + gstride * g;
         w[0] = (int32_t)groups[(size_t)g].size(), w[1] = (int32_t)load[(size_t)g], w[2] = w[3] = 0;
@@ -2041,6 +2124,11 @@ extern "C" int64_t ssi_attn_plan_build(const int32_t* host_doc_row, const int32_
         }
     }
     return words;
+}
+
+extern "C" int64_t ssi_attn_plan_workspace_bytes(const int32_t* host_plan_header) {
+    if (!host_plan_header || host_plan_header[0] != PLAN_MAGIC) return -1;
+    return (int64_t)host_plan_header[15] * host_plan_header[9] * 256 * 128 * (int64_t)sizeof(float);
 }
 
 static std::atomic<int> g_last_dispatch{0};
@@ -2110,14 +2198,26 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
     const bool balanced = per0 * rep * 256 <= total_tiles * 23 / 20 || sel == SSI_ATTN_MODE_NEW;
     const bool v2 = !doc_end && seq % 256 == 0 && rep % 4 == 0 && (seq / 32) * rep <= DKV2_MAX_STEPS && balanced && sel != SSI_ATTN_MODE_OLD;
     if (ph && sel != SSI_ATTN_MODE_OLD) {
+        const int64_t want = ssi_attn_plan_workspace_bytes(ph);
+        if (want > 0 && (!workspace || workspace_bytes < want || ((uintptr_t)workspace & 15))) {
+            ssi_set_error("ssi_attn_varlen_bwd_plan: the plan splits %d chunks over the query heads and needs %lld bytes of workspace (got %lld)", ph[13],
+                          (long long)want, (long long)workspace_bytes);
+            return SSI_ERR_WORKSPACE;
+        }
         hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, dim3((unsigned)(ph[1] * n_kv)), dim3(256), 0, st, (const bf16_t*)qkv, ld, (const bf16_t*)dout, lse,
                            delta, (bf16_t*)dqkv, rope, positions, (int)seq, n_heads, n_kv, reinterpret_cast<const int4*>(plan_dev + ph[2]),
-                           reinterpret_cast<const float*>(plan_dev + 12));
+                           reinterpret_cast<const float*>(plan_dev + 12), (float*)workspace);
         used |= SSI_ATTN_USED_DKV2 | SSI_ATTN_USED_PLAN;
+        if (ph[13] > 0) {
+            SSI_LAUNCH_CHECK();
+            hipLaunchKernelGGL(attn_dkv_plan_reduce_kernel, dim3((unsigned)(ph[13] * n_kv * 32)), dim3(256), 0, st, (const float*)workspace,
+                               reinterpret_cast<const int4*>(plan_dev + ph[14]), n_kv, (bf16_t*)dqkv, ld, n_heads, rope, positions, (int)seq);
+            used |= SSI_ATTN_USED_HEAD_SPLIT;
+        }
     } else if (v2) {
         hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, dim3((unsigned)(batch * n_kv * (seq / 256))), dim3(256), 0, st, (const bf16_t*)qkv, ld,
                            (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, rope, positions, (int)seq, n_heads, n_kv, (const int4*)nullptr,
-                           (const float*)nullptr);
+                           (const float*)nullptr, (float*)nullptr);
         used |= SSI_ATTN_USED_DKV2;
     } else {
         // small launches: one workgroup per query head + a reduction, when the caller brought the workspace (mode NO_HEAD_SPLIT: never)

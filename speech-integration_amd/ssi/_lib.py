@@ -24,7 +24,7 @@ ABI_VERSION = 7
 ATTN_KERNEL_DQ, ATTN_KERNEL_DKV = 0, 1
 ATTN_MODE_AUTO, ATTN_MODE_OLD, ATTN_MODE_NEW, ATTN_MODE_NO_HEAD_SPLIT = 0, 1, 2, 3
 ATTN_USED_DQ2, ATTN_USED_DKV2, ATTN_USED_HEAD_SPLIT, ATTN_USED_PLAN = 1, 2, 4, 8
-ATTN_PLAN_HEADER, ATTN_PLAN_FORCE = 16, 1
+ATTN_PLAN_HEADER, ATTN_PLAN_FORCE, ATTN_PLAN_SPLIT_ALL = 16, 1, 2
 
 # name -> (restype, argtypes); mirrors include/ssi_hip.h line by line
 _P = c_void_p
@@ -54,6 +54,7 @@ PROTOTYPES = {
     "ssi_attn_varlen_bwd_ws": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int, c_int, c_int,
                                        c_int, _P, c_int64, _P]),
     "ssi_attn_plan_words": (c_int64, [c_int64, c_int64, c_int64]),
+    "ssi_attn_plan_workspace_bytes": (c_int64, [_P]),
     "ssi_attn_plan_build": (c_int64, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P, c_int64]),
     "ssi_attn_varlen_bwd_plan": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int, c_int, c_int,
                                          c_int, _P, c_int64, _P, _P, _P]),

@@ -47,6 +47,11 @@ class AttnPlan:
     def n_dq_groups(self) -> int:
         return int(self.host[3])
 
+    @property
+    def workspace_bytes(self) -> int:
+        """What the backward needs in its workspace for this plan: fp32 partial rows of the dK/dV chunks split over the query heads."""
+        return int(self.host[15]) * int(self.host[9]) * 256 * 128 * 4
+
     def matches(self, batch: int, seq: int, n_heads: int, n_kv: int) -> bool:
         h = self.host
         return int(h[6]) == batch and int(h[7]) == seq and int(h[8]) == n_heads and int(h[9]) == n_kv
@@ -70,9 +75,10 @@ class AttnPlan:
             out.append([tuple(h[base + 4 + 4 * i: base + 8 + 4 * i]) for i in range(n)])
         return out
 
-    def dkv_items(self) -> list[tuple[int, int, int, int]]:
+    def dkv_items(self, with_heads: bool = False) -> list[tuple]:
+        """(row, first key, document start, document end) per dK/dV workgroup; ``with_heads``: + (first query head, query heads, partial slot)."""
         h = self.host.tolist()
-        return [tuple(h[h[2] + 4 * i: h[2] + 4 * i + 4]) for i in range(h[1])]
+        return [tuple(h[h[2] + 8 * i: h[2] + 8 * i + (7 if with_heads else 4)]) for i in range(h[1])]
 
 
 def documents_from_input_pos(input_pos: Tensor) -> Optional[tuple[Tensor, Tensor, Tensor]]:
@@ -95,7 +101,8 @@ def documents_from_input_pos(input_pos: Tensor) -> Optional[tuple[Tensor, Tensor
     return rows.to(torch.int32).contiguous(), starts.to(torch.int32).contiguous(), ends.to(torch.int32).contiguous()
 
 
-def build_plan(rows: Tensor, starts: Tensor, ends: Tensor, batch: int, seq: int, n_heads: int, n_kv: int, force: bool = False) -> Optional[AttnPlan]:
+def build_plan(rows: Tensor, starts: Tensor, ends: Tensor, batch: int, seq: int, n_heads: int, n_kv: int, force: bool = False,
+               split_all: bool = False) -> Optional[AttnPlan]:
     """``None`` when the library says the round-1..3 kernels should keep this batch (``ssi_attn_plan_build`` returns 0)."""
     lib = _lib.load()
     n_docs = int(rows.numel())
@@ -106,7 +113,7 @@ def build_plan(rows: Tensor, starts: Tensor, ends: Tensor, batch: int, seq: int,
     words = int(lib.ssi_attn_plan_words(batch, seq, n_docs))
     host = torch.empty(words, dtype=torch.int32)
     used = int(lib.ssi_attn_plan_build(rows.data_ptr(), starts.data_ptr(), ends.data_ptr(), n_docs, batch, seq, n_heads, n_kv,
-                                       _lib.ATTN_PLAN_FORCE if force else 0, host.data_ptr(), words))
+                                       (_lib.ATTN_PLAN_FORCE if force else 0) | (_lib.ATTN_PLAN_SPLIT_ALL if split_all else 0), host.data_ptr(), words))
     if used < 0:
         raise ValueError(f"ssi_attn_plan_build refused the documents of a [{batch}, {seq}] batch ({n_docs} documents): they must tile every row")
     if used == 0:
@@ -122,7 +129,7 @@ def plan_from_input_pos(input_pos: Tensor, n_heads: int, n_kv: int, force: bool 
     return build_plan(*docs, B, S, n_heads, n_kv, force=force)
 
 
-def plan_from_seq_lens(seq_lens_rows: list[list[int]], n_heads: int, n_kv: int, force: bool = False) -> Optional[AttnPlan]:
+def plan_from_seq_lens(seq_lens_rows: list[list[int]], n_heads: int, n_kv: int, force: bool = False, split_all: bool = False) -> Optional[AttnPlan]:
     """Documents given as per-row lists of lengths (every row sums to the same S)."""
     rows, starts, ends = [], [], []
     S = sum(seq_lens_rows[0])
@@ -133,4 +140,4 @@ def plan_from_seq_lens(seq_lens_rows: list[list[int]], n_heads: int, n_kv: int, 
             rows.append(b), starts.append(o), ends.append(o + n)
             o += n
     t = lambda x: torch.tensor(x, dtype=torch.int32)  # noqa: E731
-    return build_plan(t(rows), t(starts), t(ends), len(seq_lens_rows), S, n_heads, n_kv, force=force)
+    return build_plan(t(rows), t(starts), t(ends), len(seq_lens_rows), S, n_heads, n_kv, force=force, split_all=split_all)

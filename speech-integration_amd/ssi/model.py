@@ -567,6 +567,8 @@ class HipLlamaDecoder(nn.Module):
 
         # small micro-batches: dK / dV per query head + a reduction, in a workspace of the arena (0 bytes = the launch fills the chip as it is)
         ws_bytes = ops.attn_bwd_workspace_bytes(B, S, H, KV, hd, dt) if T > 0 else 0
+        if plan is not None:  # (partial rows of the dK/dV chunks a plan splits over the query heads)
+            ws_bytes = max(ws_bytes, plan.workspace_bytes)
         attn_ws = A.get("ws.attn", (ws_bytes,), torch.uint8) if ws_bytes else None
         dh = A.get("dh.a", (T, D), dt)
         ops.rmsnorm_bwd(d_hn, A.get(f"h{L}", (T, D), dt), self.norm.scale, A.get("rstdf", (T,), torch.float32), None, dh,

@@ -164,6 +164,9 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, dqkv: Tensor, 
         table_len = rope_table.shape[0] if rope_table is not None else 0
         if plan is not None:
             assert ds is not None and plan.dev is not None and plan.dev.device == qkv.device and plan.matches(batch, seq, n_heads, n_kv)
+            if ws_bytes < plan.workspace_bytes:  # fp32 partial rows of the dK/dV chunks the plan splits over the query heads
+                workspace = _byte_ws(plan.workspace_bytes, qkv)
+                ws_bytes = workspace.numel()
             check(_lib.load().ssi_attn_varlen_bwd_plan(ptr(qkv), qkv.stride(0), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), ds, de,
                                                        ptr(rope_table), table_len, ptr(positions), batch, seq, n_heads, n_kv, head_dim,
                                                        dtype_code(qkv.dtype), ptr(workspace), ws_bytes, ptr(plan.dev), plan.host.data_ptr(),

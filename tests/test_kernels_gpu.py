@@ -751,23 +751,29 @@ PLAN_CASES = [
 
 
 @pytest.mark.parametrize("B,S,H,KV,rows", PLAN_CASES, ids=[f"{c[0]}x{c[1]}-{len(c[4][0])}docs" for c in PLAN_CASES])
-@pytest.mark.parametrize("fused_rope", [False, True])
-def test_attention_plan_kernels_on_packed_rows(ops, B, S, H, KV, rows, fused_rope, attn_impl):
+@pytest.mark.parametrize("fused_rope,split_all", [(False, False), (True, False), (True, True)], ids=["plain-epilogue", "fused-rope", "fused-rope-every-chunk-split"])
+def test_attention_plan_kernels_on_packed_rows(ops, B, S, H, KV, rows, fused_rope, split_all, attn_impl):
     """Round 5: packed rows on the pipelined backward kernels (document-aware forms: attn_bwd_dq2_kernel<0, true>, attn_bwd_dkv2_kernel<true>)
     from a host-built work plan (ssi_attn_plan_build): against torch SDPA with the dense block mask in fp32, against the plan-less call (the
     round-1..3 kernels: another order of the fp32 sums), reproducible, the dispatch asserted; with the fused RoPE backward the positions are
-    document-relative (the plan's assumption).  Documents must not leak: perturbing one leaves the others' gradients bit-identical."""
+    document-relative (the plan's assumption).  Documents must not leak: perturbing one leaves the others' gradients bit-identical.
+    ``split_all``: every dK/dV chunk split over the query heads (2 x 2 or 4 x 1 heads alternating; the builder does this to chunks heavier than
+    the chip's share per compute unit): fp32 partial sums + the reduction pass, and — with 1 or 2 heads per workgroup — tile counts that are
+    no multiple of 4, i.e. the dummy tiles that pad a loop to whole trips."""
     from ssi import _lib, attn_plan
     hd = 64
     qkv = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=141)
     do = rnd(B * S, H * hd, dtype=torch.bfloat16, seed=142)
     ds, de = (t.to(DEV) for t in _doc_arrays(rows, S))
-    plan = attn_plan.plan_from_seq_lens(rows, H, KV, force=True)
+    plan = attn_plan.plan_from_seq_lens(rows, H, KV, force=True, split_all=split_all)
     assert plan is not None and plan.matches(B, S, H, KV)
-    # every key belongs to exactly one dK/dV item, every query to exactly one dQ item
+    assert plan.workspace_bytes > 0 or not split_all
+    # every (key, query head) belongs to exactly one dK/dV item, every query to exactly one dQ item
     seen_k, seen_q = torch.zeros(B, S, dtype=torch.int32), torch.zeros(B, S, dtype=torch.int32)
-    for b, k0, d0, d1 in plan.dkv_items():
-        seen_k[b, max(k0, d0):min(k0 + 256, d1)] += 1
+    for b, k0, d0, d1, _, heads, slot in plan.dkv_items(with_heads=True):
+        assert (slot >= 0) == (heads < 4)
+        seen_k[b, max(k0, d0):min(k0 + 256, d1)] += heads
+    seen_k //= 4
     for grp in plan.dq_groups():
         for b, q0, d0, d1 in grp:
             seen_q[b, max(q0, d0):min(q0 + 64, d1)] += 1
@@ -788,6 +794,8 @@ def test_attention_plan_kernels_on_packed_rows(ops, B, S, H, KV, rows, fused_rop
         used = ops.attn_last_dispatch()
         want = _lib.ATTN_USED_DQ2 | _lib.ATTN_USED_DKV2 | _lib.ATTN_USED_PLAN
         assert (used & want) == (want if plan_ is not None else 0), hex(used)
+        if plan_ is not None:
+            assert bool(used & _lib.ATTN_USED_HEAD_SPLIT) == (plan_.workspace_bytes > 0), hex(used)
         return d.cpu().float()
 
     prev = ops.set_impl(_lib.IMPL_MFMA)
@@ -817,13 +825,14 @@ def test_attention_plan_kernels_on_packed_rows(ops, B, S, H, KV, rows, fused_rop
 
 
 def test_attention_plan_builder_declines_what_the_old_kernels_do_better(ops):
-    """ssi_attn_plan_build returns no plan for head ratios other than 4, mostly tiny documents, a few long documents and nothing else (there
-    the 128-key kernel's split over the query heads wins), documents beyond the tile table; a plan that belongs to another batch is refused
-    by the launch; documents that do not tile the rows are an error."""
+    """ssi_attn_plan_build returns no plan for head ratios other than 4, mostly tiny documents, documents beyond the tile table; a plan
+    that belongs to another batch is refused by the launch; documents that do not tile the rows are an error."""
     from ssi import attn_plan
     assert attn_plan.plan_from_seq_lens([[700, 31, 1100, 217]], 8, 4) is None
     assert attn_plan.plan_from_seq_lens([[5] * 76 + [4]], 4, 1) is None
-    assert attn_plan.plan_from_seq_lens([[2048], [2048]], 32, 8) is None
+    two_long = attn_plan.plan_from_seq_lens([[2048], [2048]], 32, 8)   # a few long documents: their heavy chunks are split over the query heads
+    assert two_long is not None and two_long.workspace_bytes > 0 and max(h for *_, h, _ in two_long.dkv_items(True)) == 4
+    assert min(h for *_, h, _ in two_long.dkv_items(True)) == 1
     assert attn_plan.plan_from_seq_lens([[2048]] * 8, 32, 8) is not None
     assert attn_plan.plan_from_seq_lens([[32768]], 32, 8) is None
     assert attn_plan.plan_from_seq_lens([[1807, 2038, 1909, 1924, 1500, 2048, 294]], 32, 8) is not None
