@@ -183,8 +183,10 @@ int64_t ssi_attn_plan_workspace_bytes(const int32_t* host_plan_header);
 int64_t ssi_attn_plan_build(const int32_t* host_doc_row, const int32_t* host_doc_start, const int32_t* host_doc_end, int64_t n_docs,
                             int64_t batch, int64_t seq, int n_heads, int n_kv, int flags, int32_t* host_plan, int64_t plan_words);
 /* ssi_attn_varlen_bwd_ws + a plan: plan = the plan in DEVICE memory, host_plan_header = its first SSI_ATTN_PLAN_HEADER words on the host
- * (both NULL = ssi_attn_varlen_bwd_ws).  doc_start / doc_end stay required (kernels a mode switch sends back to the round-1..3 forms read
- * them).  Results equal the plan-less call's to the rounding of another summation order; reproducible for a given plan. */
+ * (both NULL = ssi_attn_varlen_bwd_ws).  doc_start / doc_end stay required for packed rows (kernels a mode switch sends back to the
+ * round-1..3 forms read them); plain causal rows (doc_start = doc_end = positions = NULL) may bring a plan whose documents are the rows
+ * themselves — the persistent dQ workgroups then get their query blocks by load instead of by a fixed pattern.  Results equal the plan-less
+ * call's to the rounding of another summation order; reproducible for a given plan. */
 int ssi_attn_varlen_bwd_plan(const void* qkv, int64_t ld, const void* out, const void* dout, const float* lse, void* dqkv,
                              float* delta, const int32_t* doc_start, const int32_t* doc_end, const float* rope_table,
                              int64_t table_len, const int32_t* positions, int64_t batch, int64_t seq, int n_heads, int n_kv,

@@ -313,7 +313,7 @@ extern "C" int ssi_attn_varlen_bwd_plan(const void* qkv, int64_t ld, const void*
     SSI_CHECK_ARG(!rope_table || positions != nullptr || table_len >= seq);
     SSI_CHECK_ARG(workspace_bytes >= 0 && (workspace != nullptr || workspace_bytes == 0));
     SSI_CHECK_ARG((plan == nullptr) == (host_plan_header == nullptr));
-    SSI_CHECK_ARG(!plan || (doc_start && doc_end && ((uintptr_t)plan & 15) == 0));
+    SSI_CHECK_ARG(!plan || ((uintptr_t)plan & 15) == 0);
     return attn_varlen_bwd_impl(qkv, ld, out, dout, lse, dqkv, delta, doc_start, doc_end, rope_table, table_len, positions, batch, seq,
                                 n_heads, n_kv, head_dim, dtype, stream, workspace, workspace_bytes, plan, host_plan_header);
 }

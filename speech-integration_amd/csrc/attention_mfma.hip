@@ -2148,8 +2148,9 @@ int ssi_attn_bwd_mfma(const void* qkv, int64_t ld, const void* out, const void* 
     // packed rows with a plan: the document-aware forms of the pipelined kernels (mode OLD sends either kernel back to the round-1..3 one)
     const int32_t* ph = (plan_dev && host_plan_header) ? host_plan_header : nullptr;
     if (ph) {
-        if (ph[0] != PLAN_MAGIC || ph[6] != batch || ph[7] != seq || ph[8] != n_heads || ph[9] != n_kv || rep != 4 || !doc_start || !doc_end ||
-            ph[1] <= 0 || ph[3] <= 0 || (rope && table_len <= 0)) {
+        // (plain causal rows — no document arrays — take a plan whose documents are the rows themselves: the same work, dealt out by load)
+        if (ph[0] != PLAN_MAGIC || ph[6] != batch || ph[7] != seq || ph[8] != n_heads || ph[9] != n_kv || rep != 4 || ph[1] <= 0 || ph[3] <= 0 ||
+            (rope && table_len <= 0) || ((!doc_start || !doc_end) && (ph[11] != batch || positions))) {
             ssi_set_error("ssi_attn_varlen_bwd_plan: the plan does not belong to this batch (magic %x, batch %d, seq %d, heads %d / %d)", ph[0], ph[6],
                           ph[7], ph[8], ph[9]);
             return SSI_ERR_ARG;

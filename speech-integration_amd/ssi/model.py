@@ -447,11 +447,31 @@ class HipLlamaDecoder(nn.Module):
             return None
         return attn_plan.plan_from_input_pos(input_pos, self.num_heads, self.num_kv_heads, force=force)
 
+    # SSI_PLAIN_PLAN=1 (A/B runs): plain causal rows with a work plan too instead of the dispatcher's fixed patterns.  Measured and left off:
+    # 0.2-0.3 % slower in the step at 8 x 2048, 2 x 2048, 16 x 768 and 8 x 4096 (profiles/LAB_NOTES.md, round 5) — equal rows need no balancing
+    plan_plain_rows = os.environ.get("SSI_PLAIN_PLAN", "0") == "1"
+
+    def _plain_rows_plan(self, B: int, S: int, device):
+        """Work plan for plain causal rows — every row one document — built once per batch shape and kept on the device: the attention
+        backward's persistent dQ workgroups then take their query blocks by load (the host's longest-processing-time assignment) and dK / dV
+        chunks heavier than the chip's share per compute unit are split over the query heads, whatever B and S are."""
+        cache = self.__dict__.setdefault("_plain_plans", {})
+        key = (B, S, str(device))
+        if key not in cache:
+            from . import attn_plan
+            plan = None
+            if self.head_dim == 64 and self.num_heads == 4 * self.num_kv_heads and S % 128 == 0:
+                plan = attn_plan.plan_from_seq_lens([[S]] * B, self.num_heads, self.num_kv_heads)
+            cache[key] = plan.to_device(device, non_blocking=False) if plan is not None else None
+        return cache[key]
+
     def _forward_hidden(self, tokens: Tensor, save: bool, input_pos: Optional[Tensor] = None, attn_plan=None) -> Tensor:
         B, S = tokens.shape
         pos = ds = de = None
         self.position_errors = None
         plan = None
+        if input_pos is None and save and self.plan_plain_rows and self._mfma_shapes():
+            plan = self._plain_rows_plan(B, S, tokens.device)
         if input_pos is not None and save:
             if attn_plan is None and not input_pos.is_cuda:  # host positions: the plan costs no device sync (the trainer's prefetch thread
                 attn_plan = self.build_attn_plan(input_pos)   # brings one along with the batch instead)

@@ -163,7 +163,8 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, dqkv: Tensor, 
         ws_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
         table_len = rope_table.shape[0] if rope_table is not None else 0
         if plan is not None:
-            assert ds is not None and plan.dev is not None and plan.dev.device == qkv.device and plan.matches(batch, seq, n_heads, n_kv)
+            assert plan.dev is not None and plan.dev.device == qkv.device and plan.matches(batch, seq, n_heads, n_kv)
+            assert ds is not None or (positions is None and int(plan.host[11]) == batch), "a plan for plain rows has one document per row"
             if ws_bytes < plan.workspace_bytes:  # fp32 partial rows of the dK/dV chunks the plan splits over the query heads
                 workspace = _byte_ws(plan.workspace_bytes, qkv)
                 ws_bytes = workspace.numel()

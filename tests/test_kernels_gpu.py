@@ -824,6 +824,46 @@ def test_attention_plan_kernels_on_packed_rows(ops, B, S, H, KV, rows, fused_rop
         assert float((new - qr.grad).norm() / qr.grad.norm()) <= 1.5e-2
 
 
+@pytest.mark.parametrize("B,S,H,KV", [(2, 2048, 32, 8), (8, 512, 8, 2), (3, 640, 4, 1)])
+def test_attention_plan_for_plain_causal_rows(ops, B, S, H, KV):
+    """Plain causal rows (no document arrays, no positions) with a plan whose documents are the rows: the document-aware kernels on the same
+    work as the plain forms — dQ bit-identical to the plain pipelined kernel's (same products, same order per query block; only the blocks are
+    dealt to the workgroups by load), dK / dV equal to the rounding of the sums over the query heads where the plan splits a chunk (B = 2:
+    heavy chunks, the chip's share per compute unit is small) and bit-identical where it does not; a plan with several documents per row is
+    refused without document arrays."""
+    from ssi import _lib, attn_plan
+    hd = 64
+    x = rnd(B * S, (H + 2 * KV) * hd, dtype=torch.bfloat16, seed=171).to(DEV)
+    dout = rnd(B * S, H * hd, dtype=torch.bfloat16, seed=172).to(DEV)
+    table = rnd(S + 8, hd // 2, 2, dtype=torch.float32, seed=173).to(DEV)
+    plan = attn_plan.plan_from_seq_lens([[S]] * B, H, KV, force=True).to_device(DEV)
+    prev = ops.set_impl(_lib.IMPL_MFMA)
+    saved = [ops.set_attn_impl(_lib.ATTN_KERNEL_DQ, _lib.ATTN_MODE_NEW), ops.set_attn_impl(_lib.ATTN_KERNEL_DKV, _lib.ATTN_MODE_NEW)]
+    try:
+        out = torch.empty(B * S, H * hd, dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B * H * S, dtype=torch.float32, device=DEV)
+        ops.attn_fwd(x, out, lse, B, S, H, KV, hd)
+        res = []
+        for p_ in (None, plan, plan):
+            d = torch.full_like(x, float("nan"))
+            ops.attn_bwd(x, out, dout, lse, d, torch.empty_like(lse), B, S, H, KV, hd, rope_table=table, plan=p_)
+            assert bool(ops.attn_last_dispatch() & _lib.ATTN_USED_PLAN) == (p_ is not None)
+            res.append(d.cpu().float())
+        two_docs = attn_plan.plan_from_seq_lens([[S // 2, S // 2]] * B, H, KV, force=True).to_device(DEV)
+        with pytest.raises(AssertionError):
+            ops.attn_bwd(x, out, dout, lse, torch.empty_like(x), torch.empty_like(lse), B, S, H, KV, hd, plan=two_docs)
+    finally:
+        ops.set_impl(prev)
+        ops.set_attn_impl(_lib.ATTN_KERNEL_DQ, saved[0]), ops.set_attn_impl(_lib.ATTN_KERNEL_DKV, saved[1])
+    plain, with_plan, again = res
+    assert torch.isfinite(with_plan).all() and torch.equal(with_plan, again)
+    assert torch.equal(plain[:, : H * hd], with_plan[:, : H * hd]), "dQ: same products in the same order per query block"
+    a, b = plain[:, H * hd:], with_plan[:, H * hd:]
+    if S % 256 == 0 and plan.workspace_bytes == 0:
+        assert torch.equal(a, b), "dK / dV: unsplit chunks are the plain kernel's key groups"
+    assert float((a - b).norm() / a.norm()) <= 3e-4 and float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max())
+
+
 def test_attention_plan_builder_declines_what_the_old_kernels_do_better(ops):
     """ssi_attn_plan_build returns no plan for head ratios other than 4, mostly tiny documents, documents beyond the tile table; a plan
     that belongs to another batch is refused by the launch; documents that do not tile the rows are an error."""
