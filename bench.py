@@ -270,7 +270,7 @@ def through_trainer(args, result_out) -> int:
             f"tokenizer.max_seq_len={args.seq}", f"data.train.dataset.n_samples={steps * ga * args.batch}", "data.dev.dataset.n_samples=8",
             f"data.train.dataloader.batch_size={args.batch}", "eval_steps=1000000000", "save_steps=1000000000", f"output_dir={tmp}",
             f"checkpointer.output_dir={tmp}/ckpt", f"checkpointer.checkpoint_dir={tmp}/none", "checkpointer.allow_random_init=true",
-            f"speech.n_dsus={args.n_dsus}"])
+            f"speech.n_dsus={args.n_dsus}"] + (["data.train.dataset.fixed_len=false"] if args.padded else []))
         resolve_n_dsus(cfg)
         t = Trainer(cfg)
         t.setup()
@@ -287,6 +287,13 @@ def through_trainer(args, result_out) -> int:
             "positions_per_second": sum(ga * args.batch * args.seq / d for d in dur) / len(dur),
             "ms_per_optimizer_step": 1e3 * sum(dur) / len(dur), "ms_per_micro_batch": 1e3 * sum(dur) / len(dur) / ga,
             "steps": len(rec), "warmup": args.warmup, "train_wall_s": wall, "last_loss": rec[-1]["loss"]}
+        if args.padded:  # ragged rows: the prefetch thread dropped the padding and built the attention backward's work plan beside each batch
+            from ssi import _lib as _l, ops as _o
+            used = _o.attn_last_dispatch()
+            runs[f"grad_accum_{ga}"].update({
+                "micro_batches_run_without_their_padding": t.unpadded_micro_batches,
+                "attention_backward_of_the_last_micro_batch": {"dq2": bool(used & _l.ATTN_USED_DQ2), "dkv2": bool(used & _l.ATTN_USED_DKV2),
+                                                               "work_plan": bool(used & _l.ATTN_USED_PLAN), "head_split": bool(used & _l.ATTN_USED_HEAD_SPLIT)}})
         t.cleanup()
         del t
         torch.cuda.empty_cache()
@@ -295,7 +302,8 @@ def through_trainer(args, result_out) -> int:
                       "data": "synthetic", "higher_is_better": True,
                       "config": {"workload": f"scripts/train_sft.py path: compose(conf/sft.yaml) -> Trainer.setup() -> Trainer.train(); Llama-3.2-1B "
                                              f"+{args.n_dsus} DSUs, seq_len={args.seq}, batch={args.batch}, prefetcher on, log_interval=1, 16 layers, "
-                                             "random-init weights, MLS-shaped synthetic DSU sequences"},
+                                             "random-init weights, MLS-shaped synthetic DSU sequences"
+                                             + (", rows of unequal length right-padded by the collate function (the reference's batch format)" if args.padded else "")},
                       "value": runs["grad_accum_1"]["positions_per_second"], "runs": runs}))
     return 0
 

@@ -687,8 +687,9 @@ def test_full_size_model_on_long_rows(name, n_dsus, B, S, packed):
         # what the dispatcher picks for them — same products, another order of the fp32 sums: 1e-4 relative apart per kernel call, 0.3 % of
         # the bf16 results a step apart, and 16 layers of bf16 re-rounding on top.  Measured at HEAD of round 5: see ONE_DOC_VS_PLAIN (the
         # bound is 1.5 x the measurement; the bf16 model is 4.4e-2 from the fp32 oracle at this shape, a wrong kernel O(1)).  That the growth
-        # is re-rounding and not a kernel is shown on ONE layer below (<= 1e-3), and with the SAME kernels on both sides — a HOST input_pos
-        # gets its plan, the switches force the pipelined kernels for both — the 16-layer gradients are equal bit for bit.
+        # is re-rounding and not a kernel is shown on ONE layer below (<= 1e-3); with the pipelined kernels on both sides — a HOST input_pos
+        # gets its plan, the switches force the pipelined kernels for the plain rows — only the split of the heavy dK / dV chunks over the
+        # query heads differs (6.5e-3 over 16 layers).
         assert lo == lp
         rel = float((go.float() - gp.float()).norm() / gp.float().norm())
         print(f"[one document per row vs plain rows, 16 layers, round-1..3 kernels vs dispatcher's] {rel:.3e}")
@@ -707,7 +708,11 @@ def test_full_size_model_on_long_rows(name, n_dsus, B, S, packed):
             ops.set_attn_impl(_lib.ATTN_KERNEL_DQ, prev[0]), ops.set_attn_impl(_lib.ATTN_KERNEL_DKV, prev[1])
         both = _lib.ATTN_USED_DQ2 | _lib.ATTN_USED_DKV2
         assert used_plain & both == both and used_doc & (both | _lib.ATTN_USED_PLAN) == both | _lib.ATTN_USED_PLAN, (hex(used_plain), hex(used_doc))
-        assert loh == lpn and torch.equal(goh, gpn), float((goh.float() - gpn.float()).norm() / gpn.float().norm())
+        # (the plan of ONE 8192-token document splits its heavy dK / dV chunks over the query heads — another order of those sums; without a
+        #  split the gradients are equal bit for bit: tests/test_kernels_gpu.py::test_attention_plan_for_plain_causal_rows holds that per kernel)
+        relh = float((goh.float() - gpn.float()).norm() / gpn.float().norm())
+        print(f"[one document per row, work plan vs plain rows, pipelined kernels on both sides] {relh:.3e} (plan splits {one_doc_host['attn_plan'].workspace_bytes > 0})")
+        assert loh == lpn and (torch.equal(goh, gpn) if one_doc_host["attn_plan"].workspace_bytes == 0 else relh <= ONE_DOC_VS_PLAIN), relh
 
 
 ONE_DOC_VS_PLAIN = 1.4e-2   # 1.5 x 9.07e-3, measured at HEAD of round 5 (gpurun_out/r05_t2.log; the same 9.07e-3 as before round 4's end-of-kernel
