@@ -35,3 +35,21 @@ for f in sorted(glob.glob("gpurun_out/${tag}_sec_*.json")):
     os.remove(f)
 json.dump(out, open("gpurun_out/${tag}_secondary.json", "w"), indent=1)
 PY
+if [ "$2" = "headline" ]; then
+# per-kernel counters (three separate --pmc passes, never combined with trace domains other than the kernel trace): the headline's table, and the
+# attention kernels of the right-padded workload (document-aware forms of the pipelined backward)
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-timing"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${tag}_sq -- $CMD > gpurun_out/${tag}_sq.log 2>&1; echo "sq rc=$?"
+python tools/pmc_table.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write gpurun_out/${tag}_sq gpurun_out/${tag}_pmc_kernels.md "${tag}: per-kernel counters of \`$CMD\` at HEAD" 16 > /dev/null; echo "table rc=$?"
+for pass in fetch:FETCH_SIZE write:WRITE_SIZE sq:"SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
+  name=${pass%%:*}; ctrs=${pass#*:}
+  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/${tag}_pad_$name -- $CMD --padded > gpurun_out/${tag}_pad_$name.log 2>&1; echo "padded $name rc=$?"
+done
+python tools/pmc_table.py gpurun_out/${tag}_pad_fetch gpurun_out/${tag}_pad_write gpurun_out/${tag}_pad_sq gpurun_out/${tag}_attn_pmc.md "${tag}: attention kernels of \`$CMD --padded\` (right-padded batch, padding dropped on the host, work plan) at HEAD" 8 attn_ > /dev/null; echo "attn table rc=$?"
+cat gpurun_out/${tag}_attn_pmc.md | cut -c1-260
+rm -rf gpurun_out/${tag}_fetch/*/*agent_info.csv gpurun_out/${tag}_pad_*/*/*agent_info.csv
+bash tools/r05_prof.sh ${tag}_padded --padded
+bash tools/r05_prof.sh ${tag}_packed --packed --seq 8192 --batch 2 --n-dsus 2048
+python bench.py --through-trainer --padded --steps 8 --warmup 3 > gpurun_out/${tag}_through_trainer_padded.json 2>/dev/null; echo "through-trainer padded rc=$?"
+python bench.py --through-trainer --steps 8 --warmup 3 > gpurun_out/${tag}_through_trainer.json 2>/dev/null; echo "through-trainer rc=$?"
+fi
