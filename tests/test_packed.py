@@ -115,3 +115,54 @@ def test_device_prefetcher_order_passthrough_and_errors():
     assert ld.produced <= 3 + 1 + 2 + 1  # consumed + in hand + queue depth + one being produced
     with pytest.raises(ValueError):
         DevicePrefetcher(Loader(1), "cpu", depth=0)
+
+
+def test_attention_work_plans_cover_every_position_exactly_once_on_random_document_layouts():
+    """``ssi_attn_plan_build`` (host code of the library, no GPU needed) on 60 random layouts — 1-token documents, documents on and off the
+    32 / 64 / 256-row grids, one to four rows, long rows of short documents and short rows of long ones: every (key, query head) belongs to
+    exactly one dK/dV workgroup and every query to exactly one dQ item; items start on their grids and lie inside their documents' reach;
+    dK/dV workgroups come heaviest first, a dQ group's items heaviest first, the groups' loads within one heaviest item of each other
+    (longest-processing-time); split chunks have their slots counted in the header; building twice gives the same plan."""
+    import random
+    import torch
+    from ssi import attn_plan
+    rnd = random.Random(7)
+    for case in range(60):
+        B, S = rnd.choice([1, 1, 2, 4]), 128 * rnd.choice([1, 2, 3, 8, 16, 45, 64])
+        hi = rnd.choice([3, 40, 300, 1100, 4000])
+        rows = []
+        for _ in range(B):
+            lens, left = [], S
+            while left:
+                n = min(left, rnd.randint(1, hi))
+                lens.append(n)
+                left -= n
+            rows.append(lens)
+        plan = attn_plan.plan_from_seq_lens(rows, 32, 8, force=True, split_all=case % 5 == 0)
+        again = attn_plan.plan_from_seq_lens(rows, 32, 8, force=True, split_all=case % 5 == 0)
+        assert plan is not None and torch.equal(plan.host, again.host)
+        cover_k, cover_q = torch.zeros(B, S, dtype=torch.int32), torch.zeros(B, S, dtype=torch.int32)
+        works, slots = [], set()
+        for b, k0, d0, d1, h0, heads, slot in plan.dkv_items(with_heads=True):
+            assert k0 % 32 == 0 and 0 <= d0 < d1 <= S and k0 < d1
+            assert k0 >= (d0 & ~31) and (k0 - (d0 & ~31)) % 256 == 0 and heads in (1, 2, 4) and h0 % heads == 0 and h0 + heads <= 4
+            assert (slot >= 0) == (heads < 4)
+            if slot >= 0:
+                assert slot not in slots
+                slots.add(slot)
+            cover_k[b, max(k0, d0):min(k0 + 256, d1)] += heads
+            works.append((-(-d1 // 32) - k0 // 32) * heads)
+        assert bool((cover_k == 4).all()), (case, rows)
+        assert works == sorted(works, reverse=True)
+        assert plan.workspace_bytes == len(slots) * 8 * 256 * 128 * 4 and (not slots or slots == set(range(len(slots))))
+        loads, heaviest = [], 0
+        for grp in plan.dq_groups():
+            w = [q0 // 64 - d0 // 64 + 1 for _, q0, d0, _ in grp]
+            assert grp and w == sorted(w, reverse=True)
+            loads.append(sum(x + 6 for x in w))
+            heaviest = max(heaviest, max(w) + 6)
+            for b, q0, d0, d1 in grp:
+                assert q0 % 64 == 0 and q0 >= (d0 & ~63) and q0 < d1
+                cover_q[b, max(q0, d0):min(q0 + 64, d1)] += 1
+        assert bool((cover_q == 1).all()), (case, rows)
+        assert max(loads) - min(loads) <= heaviest, (case, loads)
