@@ -427,13 +427,18 @@ def main() -> int:
         timer.install()
 
     ga = max(1, args.grad_accum)
+    overlap_adamw = os.environ.get("SSI_ADAMW_OVERLAP", "1") != "0" and sync is None   # (A/B switch; what the trainer does when it does not clip)
 
     def one_step(i: int) -> tuple[float, int]:
         rows = []
+        n_dev = None
         for j in range(ga):  # the accumulation window: only its last backward exchanges gradients; counts and losses stay on the device
             b = batches[(i * ga + j) % len(batches)]
             counts = count_token_types_async(b["tokens"], ranges, pad_id, b["labels"], -100)
             model.sync_this_backward = j == ga - 1
+            n_dev = counts[-1] if n_dev is None else n_dev + counts[-1]
+            if j == ga - 1 and overlap_adamw:  # the window's token count is known on the device before its last backward: AdamW runs under it
+                opt.overlap_with_backward(1.0 / n_dev.to(torch.float32))
             loss_batch = compute_loss(loss_inputs(b) if not args.packed else b, model, loss_fn) * counts[-1]
             loss_batch.backward()
             rows.append(torch.cat((counts.double(), loss_batch.detach().double().reshape(1))))

@@ -280,7 +280,9 @@ int64_t ssi_sumsq_workspace_bytes(int64_t n);
 int ssi_sumsq(const void* x, int64_t n, int dtype, float* out, void* workspace, int64_t workspace_bytes, void* stream);
 /* Decoupled-weight-decay Adam on flat buffers, fp32 op-math, one rounding on store (torch fused AdamW semantics):
  *   g = grad * (grad_scale_dev ? *grad_scale_dev : 1);  p -= lr*wd*p;  m = m + (1-b1)(g-m);  v = b2 v + (1-b2) g g;
- *   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps),  bc1 = 1-b1^step, bc2 = 1-b2^step.  If zero_grad: grad <- 0. */
+ *   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps),  bc1 = 1-b1^step, bc2 = 1-b2^step.  zero_grad bit 0: grad <- 0; bit 1 (ABI v7): the
+ *   launch changes nothing when *grad_scale_dev is inf or NaN (1 / 0 label tokens of an accumulation window: the reference skips that window's
+ *   optimizer step, ssi/trainer.py:399-403; an update issued before the host has read the count back skips by itself). */
 int ssi_adamw_step(void* param, void* grad, void* exp_avg, void* exp_avg_sq, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int64_t step, const float* grad_scale_dev, int zero_grad,
                    int dtype, void* stream);

@@ -604,6 +604,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* __restrict__ p, T* __rest
                                                     const float* __restrict__ grad_scale_dev, int zero_grad) {
     constexpr int N = Vec16<T>::N;
     const float gs = grad_scale_dev ? *grad_scale_dev : 1.f;
+    if ((zero_grad & 2) && !(fabsf(gs) < INFINITY)) return;  // bit 1: a non-finite scale (an accumulation window without a label) changes nothing
+    zero_grad &= 1;
     const int64_t nvec = n / N;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
         Vec16<T> pp = load16_nt(p + i * N), gg = load16_nt(g + i * N), mm = load16_nt(m + i * N), vv = load16_nt(v + i * N);

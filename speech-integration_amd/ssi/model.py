@@ -239,6 +239,7 @@ class HipLlamaDecoder(nn.Module):
         self._grads_stale = False
         self._emb_grad_written = False
         self.label_errors: Optional[Tensor] = None        # device count of out-of-range labels seen by the last fused loss
+        self.bucket_listener = None                       # callable(name, lo, hi) for the NEXT gradient-exchanging backward (see _backward_hidden)
         self.position_errors: Optional[Tensor] = None     # device count of input_pos entries outside the RoPE table in the last forward
         self.grad_sync = None                             # optional ssi.distributed.GradSync
         self.sync_this_backward = False
@@ -555,7 +556,15 @@ class HipLlamaDecoder(nn.Module):
 
         sync = self.grad_sync if (self.grad_sync is not None and self.sync_this_backward) else None
         self._ensure_transposed()
-        announce = (lambda name: sync.bucket_ready(*self._bucket_by_name[name])) if sync else (lambda name: None)
+        # who hears that a bucket's gradients are final: the data-parallel exchange, and / or an optimizer that updates the bucket's parameters
+        # under the rest of this backward (HipAdamW.overlap_with_backward, one shot: set for the window's last backward)
+        listener, self.bucket_listener = (self.bucket_listener if self.sync_this_backward else None), None
+
+        def announce(name: str) -> None:
+            if sync:
+                sync.bucket_ready(*self._bucket_by_name[name])
+            if listener is not None:
+                listener(*self._bucket_by_name[name])
 
         # Weight gradients of the attention projections (dW_o = d hmid^T att: 64 output tiles; dW_qkv = d qkv^T xn1: 96): deferred until the
         # lowest layer of a group has produced its d qkv, then ONE batched launch per weight covers the group at full K (8 layers: 512 and

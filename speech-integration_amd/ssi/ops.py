@@ -382,10 +382,12 @@ def sumsq(x: Tensor, out: Tensor, workspace: Tensor | None = None) -> None:
 
 def adamw_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, *, lr: float, beta1: float, beta2: float,
                eps: float, weight_decay: float, step: int, grad_scale_dev: Tensor | None = None,
-               zero_grad: bool = False) -> None:
+               zero_grad: bool = False, skip_nonfinite_scale: bool = False) -> None:
+    """``skip_nonfinite_scale``: the launch changes nothing when ``*grad_scale_dev`` is inf or NaN (1 / 0 label tokens: the reference skips such
+    a window's optimizer step; an update issued before the host knows the count must do the same by itself)."""
     assert param.is_contiguous() and grad.is_contiguous() and exp_avg.is_contiguous() and exp_avg_sq.is_contiguous()
     assert param.numel() == grad.numel() == exp_avg.numel() == exp_avg_sq.numel()
     assert param.dtype == grad.dtype == exp_avg.dtype == exp_avg_sq.dtype
     check(_lib.load().ssi_adamw_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, beta1, beta2,
-                                     eps, weight_decay, step, ptr(grad_scale_dev), int(zero_grad), dtype_code(param.dtype),
+                                     eps, weight_decay, step, ptr(grad_scale_dev), int(zero_grad) | (2 if skip_nonfinite_scale else 0), dtype_code(param.dtype),
                                      stream_ptr()), "ssi_adamw_step")

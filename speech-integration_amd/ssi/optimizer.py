@@ -38,6 +38,8 @@ class HipAdamW(torch.optim.Optimizer):
         self._exp_avg_sq = torch.zeros_like(model._flat)
         self._step_count = 0
         self._views_ready = False
+        self._side = None    # stream of the updates that run under the backward (overlap_with_backward)
+        self._armed = None
 
     def _ensure_state_views(self) -> None:
         if self._views_ready:
@@ -51,11 +53,75 @@ class HipAdamW(torch.optim.Optimizer):
             }
         self._views_ready = True
 
+    # ---- AdamW under the backward (one GPU, no clipping) -----------------------------------------------------------------------------------
+    def overlap_with_backward(self, grad_scale_dev: Tensor) -> bool:
+        """Arm the optimizer for the window's LAST backward: every bucket of the flat gradient buffer (``HipLlamaDecoder.buckets``: the final
+        norm, each layer's MLP block, each group's attention weights, the tied embedding) is updated on a side stream the moment that backward
+        has finished its gradients, while the backward goes on — AdamW is a pure HBM pass (17 GB) and hides partly under the MFMA-bound
+        GEMMs.  ``grad_scale_dev`` = the factor ``scale_grads`` would apply afterwards (1 / the window's token count; a DEVICE scalar, so no
+        read-back is needed before the backward); ``step()`` then only joins the side stream and counts the step.  The arithmetic per element is
+        the one of ``step()`` — same kernel, same scale, same step number — so the parameters come out bit for bit the same.  Not armed (returns
+        False: the plain ``step()`` does all the work) under data parallelism (the buckets are still being reduced), with the round-1
+        zero-and-accumulate protocol, or when gradients are to be clipped (the global norm needs every gradient first): the caller decides
+        the latter by not calling this.  A window without a single label leaves a non-finite scale: the kernel then changes nothing, and the
+        caller, who learns of the empty window at its read-back, must not call ``step()`` — exactly the reference's skip."""
+        m = self.model
+        if getattr(m, "grad_sync", None) is not None or m.always_accumulate or not m._flat.is_cuda:
+            return False
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=m._flat.device)
+        self._armed = {"scale": grad_scale_dev.to(torch.float32).reshape(1), "done": [], "step": self._step_count + 1}
+        m.bucket_listener = self._bucket_final
+        return True
+
+    def _bucket_final(self, name: str, lo: int, hi: int) -> None:
+        a, g, m = self._armed, self.param_groups[0], self.model
+        if a is None or hi <= lo:
+            return
+        cur = torch.cuda.current_stream(m._flat.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            ops.adamw_step(m._flat[lo:hi], m._flat_grad[lo:hi], self._exp_avg[lo:hi], self._exp_avg_sq[lo:hi], lr=float(g["lr"]),
+                           beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], step=a["step"],
+                           grad_scale_dev=a["scale"], zero_grad=False, skip_nonfinite_scale=True)
+        a["done"].append((lo, hi))
+
+    def cancel_overlap(self) -> None:
+        """Forget an armed overlap (a window that turned out empty: its updates were no-ops by the kernel's own guard)."""
+        if self._armed is not None:
+            torch.cuda.current_stream(self.model._flat.device).wait_stream(self._side)
+        self._armed = None
+        self.model.bucket_listener = None
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         m = self.model
+        if self._armed is not None and self._armed["done"]:
+            # the buckets were updated under the backward: join the side stream, update whatever no bucket covered (nothing, by construction)
+            a, self._armed = self._armed, None
+            m.bucket_listener = None
+            torch.cuda.current_stream(m._flat.device).wait_stream(self._side)
+            self._step_count += 1
+            assert a["step"] == self._step_count
+            covered = sorted(a["done"])
+            pos, n = 0, m._flat.numel()
+            for lo, hi in covered + [(n, n)]:
+                if lo > pos:  # a gap between buckets (none in HipLlamaDecoder's layout): the plain update, same scale
+                    ops.adamw_step(m._flat[pos:lo], m._flat_grad[pos:lo], self._exp_avg[pos:lo], self._exp_avg_sq[pos:lo], lr=float(g["lr"]),
+                                   beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], step=self._step_count,
+                                   grad_scale_dev=a["scale"], zero_grad=False)
+                pos = max(pos, hi)
+            m.pending_grad_scale = None  # (scale_grads of the caller: already applied, bucket by bucket)
+            m._hip_epoch += 1
+            if self._views_ready:
+                for st in self.state.values():
+                    st["step"].fill_(float(self._step_count))
+            return loss
+        self._armed = None
         if all(p.grad is None for p, _, _ in m._param_src):
             # no backward since the last zero_grad (skipped or failed micro-batches): torch.optim.AdamW skips parameters without a
             # gradient; the never-zeroed buffer still holds the LAST window's gradients, which must not be applied a second time
@@ -161,7 +227,13 @@ def scale_grads(model, scaler: Tensor | float) -> None:
     caller's own ``torch.optim`` optimizer on the parameter views) nothing would ever consume a deferred factor, so the
     multiplication happens at once, in place, by the HIP ``scale`` kernel."""
     if hasattr(model, "_flat_grad"):
-        s = torch.as_tensor(scaler, dtype=torch.float32).reshape(1).to(model._flat_grad.device, non_blocking=True)
+        # a host scalar becomes a device scalar by a FILL kernel, not by an asynchronous copy out of a temporary host tensor (whose memory the
+        # allocator may hand out again while the copy is still queued: round 5 saw one bench.py run in eight end on a slightly different loss)
+        dev = model._flat_grad.device
+        if torch.is_tensor(scaler) and scaler.is_cuda:
+            s = scaler.to(dev, torch.float32).reshape(1)
+        else:
+            s = torch.full((1,), float(scaler), dtype=torch.float32, device=dev)
         if _hip_optimizer_of(model) is None:  # a foreign optimizer reads p.grad itself: multiply now (one pass over the flat buffer)
             sync = getattr(model, "grad_sync", None)
             if sync is not None and hasattr(sync, "finish_deferred"):

@@ -128,6 +128,7 @@ class Trainer:
     def __init__(self, cfg) -> None:
         self.cfg = cfg
         self._pending_readbacks: list[tuple[Tensor, int]] = []  # (device row of a micro-batch's counts / loss / error counts, tokens in it)
+        self._window_valid_dev: Tensor | None = None           # valid labels of the open window's micro-batches, summed on the device
         for name in self._FILLED_BY_SETUP:
             setattr(self, name, None)
         for name, zero in self._COUNTERS.items():
@@ -393,6 +394,8 @@ class Trainer:
             n_valid = (labels != ignore).sum()
         if hasattr(self.model, "sync_this_backward"):
             self.model.sync_this_backward = bool(sync_gradients)
+        if on_gpu:
+            self._arm_optimizer(n_valid, bool(sync_gradients))
         self.unpadded_micro_batches += "packed_tokens" in batch  # (the prefetch thread dropped this batch's padding: ssi/data/unpad.py)
         loss_batch = compute_loss(loss_inputs(batch), self.model, self.loss_fn) * n_valid  # mean over SHIFTED x UNSHIFTED count
         loss_batch.backward()
@@ -409,6 +412,22 @@ class Trainer:
             self._type_counts_window[tt] += c
         self._num_tokens_step += int(n_valid.item())
         self._loss_running += float(loss_batch.item())
+
+    def _arm_optimizer(self, n_valid: Tensor, last_of_window: bool) -> None:
+        """Round 5: AdamW under the window's last backward (``HipAdamW.overlap_with_backward``).  The window's token count — the divisor of
+        ``scale_grads`` (``trainer.py:404``) — is known on the DEVICE before that backward starts (the sum of the micro-batches' valid-label
+        counts), so every bucket of gradients can be applied the moment it is final, on a side stream, while the backward runs on: the same
+        kernel with the same factor and step number, i.e. the same parameters bit for bit, 1.2 ms of the headline's 105.8.  Only where nothing
+        needs all gradients first: one GPU (``overlap_with_backward`` declines under data parallelism), no clipping, ``adamw_under_backward`` not
+        switched off.  A window without a label leaves a non-finite factor: the kernel then changes nothing and ``_optimizer_step`` skips as
+        the reference does."""
+        self._window_valid_dev = n_valid if self._window_valid_dev is None else self._window_valid_dev + n_valid
+        if not last_of_window:
+            return
+        total, self._window_valid_dev = self._window_valid_dev, None
+        if (self.cfg.get("adamw_under_backward", True) and self.cfg.clip_grad_norm is None and self.world_size == 1
+                and hasattr(self.optimizer, "overlap_with_backward")):
+            self.optimizer.overlap_with_backward(1.0 / total.to(torch.float32))
 
     @staticmethod
     def _raise_on_bad_inputs(bad: dict[str, int], anywhere: int | None = None) -> None:
@@ -441,6 +460,8 @@ class Trainer:
             self._close_window(epoch, iter_idx, window_tokens)
         else:  # every label of the window ignored: nothing to learn from, nothing to count (reference: warn, drop the gradients, go on)
             LOGGER.warning("No non-ignored tokens in accumulation window; skipping optimizer step.")
+            if hasattr(self.optimizer, "cancel_overlap"):
+                self.optimizer.cancel_overlap()  # (updates issued under the backward were no-ops: the kernel's guard on the factor 1 / 0)
             self.optimizer.zero_grad(set_to_none=True)
         self._reset_step_accumulators()
         if window_tokens > 0:
@@ -510,6 +531,7 @@ class Trainer:
 
     def _reset_step_accumulators(self) -> None:
         self.loss_running, self.num_tokens_step, self.max_seq_len_step = 0.0, 0, 0
+        self._window_valid_dev = None
         self.t_step_start = time.perf_counter()
 
     # === Checkpointing ===================================================================================================

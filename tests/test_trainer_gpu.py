@@ -196,3 +196,77 @@ def test_ids_the_kernels_must_refuse_are_raised_by_the_trainer(tmp_path, what):
     with pytest.raises(IndexError, match=match):
         t.num_tokens_step                                             # ... the window's one read-back raises (here, or in _optimizer_step)
     t.cleanup()
+
+
+@pytest.mark.parametrize("dtype,model", [("fp32", SMALL), ("bf16", MFMA_SMALL)])
+def test_adamw_under_the_backward_changes_no_bit(tmp_path, dtype, model):
+    """Round 5 (``adamw_under_backward``, default on): on one GPU without clipping the trainer arms the optimizer before a window's last
+    backward, and every bucket of gradients is applied on a side stream the moment the backward has finished it.  Same kernel, same factor
+    (1 / the window's token count, taken on the device), same step number: 6 optimizer steps of 2 micro-batches through ``Trainer.train()``
+    give the same logged losses and the same final weights, bit for bit, as the run with the switch off; with clipping configured the
+    optimizer is never armed."""
+    seq = 96 if dtype == "fp32" else 128
+    runs = {}
+    for name, extra in (("on", []), ("off", ["adamw_under_backward=false"])):
+        t = _trainer(tmp_path, name, dtype=dtype, model=model, seq=seq, overrides=["max_steps=6", *extra])
+        armed = []
+        real = t.optimizer.overlap_with_backward
+        t.optimizer.overlap_with_backward = lambda s, real=real, armed=armed: (armed.append(1), real(s))[1]
+        t.train()
+        runs[name] = (list(t._loss_log), {k: v.detach().clone() for k, v in t.model.state_dict().items()}, t.optimizer._step_count, len(armed))
+        t.cleanup()
+        del t
+    (l_on, w_on, n_on, armed_on), (l_off, w_off, n_off, armed_off) = runs["on"], runs["off"]
+    assert armed_on == 6 and armed_off == 0 and n_on == n_off == 6
+    assert l_on == l_off and len(set(l_on)) == 6
+    assert all(torch.equal(w_on[k], w_off[k]) for k in w_on)
+    clip = _trainer(tmp_path, "clip", dtype=dtype, model=model, seq=seq, overrides=["max_steps=2", "clip_grad_norm=1.0"])
+    clip.optimizer.overlap_with_backward = lambda s: (_ for _ in ()).throw(AssertionError("armed although gradients are clipped"))
+    clip.train()
+    clip.cleanup()
+
+
+def test_adamw_under_the_backward_skips_a_window_without_labels():
+    """The factor 1 / 0 (a window whose labels are all ignored) reaches the kernel before the host has read the count back: the launches issued
+    under the backward must change nothing by themselves — parameters, both moments and the step count stay as they were, the window after
+    it equals the same window on an optimizer that never saw the empty one — and a backward that never comes leaves the optimizer usable."""
+    from ssi.loss import CEWithChunkedOutputLoss, compute_loss
+    from ssi.model import HipLlamaDecoder
+    from ssi.optimizer import HipAdamW, scale_grads
+    params = dict(vocab_size=300, num_layers=2, num_heads=4, num_kv_heads=2, embed_dim=64, max_seq_len=128, intermediate_dim=128)
+    g = torch.Generator().manual_seed(3)
+    batch = {"tokens": torch.randint(0, 300, (2, 64), generator=g).to(DEV)}
+    batch["labels"] = batch["tokens"].clone()
+    empty = {"tokens": batch["tokens"], "labels": torch.full_like(batch["tokens"], -100)}
+    states = []
+    for with_empty_window in (True, False):
+        torch.manual_seed(5)
+        model = HipLlamaDecoder(**params, dtype=torch.float32, device=DEV)
+        with torch.no_grad():
+            model._flat.normal_(0.0, 0.05, generator=torch.Generator(device=DEV).manual_seed(9))
+        model.train()
+        opt = HipAdamW(model.parameters(), model=model, lr=1e-2)
+        loss_fn = CEWithChunkedOutputLoss()
+        if with_empty_window:
+            before = model._flat.clone()
+            n = (empty["labels"] != -100).sum()
+            assert opt.overlap_with_backward(1.0 / n.to(torch.float32))          # 1 / 0 = inf on the device
+            (compute_loss(empty, model, loss_fn) * n).backward()                  # (loss is 0 / 0 = NaN, as the reference's)
+            opt.cancel_overlap()
+            opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            assert torch.equal(model._flat, before) and opt._step_count == 0
+            assert float(opt._exp_avg.abs().max()) == 0.0 and float(opt._exp_avg_sq.abs().max()) == 0.0
+            assert opt.overlap_with_backward(torch.ones(1, device=DEV))           # armed, but no backward follows: step() does the plain update
+        n = (batch["labels"] != -100).sum()
+        if not with_empty_window:
+            assert opt.overlap_with_backward(1.0 / n.to(torch.float32))
+        (compute_loss(batch, model, loss_fn) * n).backward()
+        scale_grads(model, 1.0 / int(n))
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        assert opt._step_count == 1
+        states.append((model._flat.clone(), opt._exp_avg.clone(), opt._exp_avg_sq.clone()))
+    for a, b in zip(*states):
+        assert torch.equal(a, b)
