@@ -172,40 +172,32 @@ def lint_kernel(k: Kernel) -> list[str]:
                 if n + 1 < len(bl):
                     s.append(n + 1)
             succ[n] = s
-        dirty_in = [False] * len(bl)
-        changed = True
-        dirty_out = [False] * len(bl)
-        while changed:
-            changed = False
-            for n, (a, b) in enumerate(bl):
-                d = dirty_in[n]
-                for i in k.ins[a:b + 1]:
-                    if is_lds_dma(i):
-                        d = True
-                    elif drains_vm(i):
-                        d = False
-                    elif i.op.startswith("s_endpgm") and d:
-                        pass
-                if d != dirty_out[n]:
-                    dirty_out[n] = d
-                    changed = True
-                for s in succ[n]:
-                    if d and not dirty_in[s]:
-                        dirty_in[s] = True
-                        changed = True
-        for n, (a, b) in enumerate(bl):
-            d = dirty_in[n]
+        def transfer(n: int, dirty: bool, report: bool = False) -> bool:
+            a, b = bl[n]
             for i in k.ins[a:b + 1]:
                 if is_lds_dma(i):
-                    d = True
+                    dirty = True
                 elif drains_vm(i):
-                    d = False
-                elif i.op.startswith("s_endpgm") and d:
+                    dirty = False
+                elif report and dirty and i.op.startswith("s_endpgm"):
                     errs.append(f"R3 {short}: s_endpgm at {i.addr:#x} reachable with LDS-DMA requests in flight (no s_waitcnt vmcnt(0) on the path)")
+            return dirty
+
+        dirty_in = [False] * len(bl)
+        work = list(range(len(bl)))
+        while work:  # to the fixed point: a block is dirty on entry if any predecessor may leave it dirty
+            n = work.pop()
+            if transfer(n, dirty_in[n]):
+                for s_ in succ[n]:
+                    if not dirty_in[s_]:
+                        dirty_in[s_] = True
+                        work.append(s_)
+        for n in range(len(bl)):
+            transfer(n, dirty_in[n], report=True)
     return errs
 
 
-def lint(lib: str = DEFAULT_LIB, verbose: bool = False) -> tuple[list[str], dict[str, dict]]:
+def lint(lib: str = DEFAULT_LIB) -> tuple[list[str], dict[str, dict]]:
     errs, report = [], {}
     with tempfile.TemporaryDirectory() as wd:
         for co in extract(lib, wd):
