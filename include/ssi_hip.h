@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-#define SSI_ABI_VERSION 7 /* 7: + ssi_set_attn_impl, ssi_attn_last_dispatch (no getenv on the launch path), ssi_attn_plan_* and ssi_attn_varlen_bwd_plan
+#define SSI_ABI_VERSION 8 /* 8: + ssi_ce_fwd_weighted (per-row loss weights: an accumulation window run as ONE batch keeps the reference's
+                           *    per-micro-batch normalisation, ssi/data/window.py)
+                           * 7: + ssi_set_attn_impl, ssi_attn_last_dispatch (no getenv on the launch path), ssi_attn_plan_* and ssi_attn_varlen_bwd_plan
                            *    (packed rows on the pipelined backward kernels, host-built work plan)
                            * 6: + ssi_attn_bwd_workspace_bytes, ssi_attn_varlen_bwd_ws (attention backward with a caller-owned workspace)
                            * 5: ssi_doc_ranges takes n_clamped (out-of-table positions are counted, not only clamped)
@@ -251,6 +253,12 @@ int ssi_ce_fwd(void* logits, int64_t ld, const int64_t* labels, int64_t rows, in
  * are not ignored and lie in [0, vocab) — the predicate ssi_ce_fwd uses), out[3] = number of out-of-range labels.  out: 4 floats. */
 int ssi_ce_reduce(const float* row_loss, const int64_t* labels, int64_t rows, int64_t vocab, int64_t ignore_index, float* out,
                   void* stream);
+/* ssi_ce_fwd with a weight per row (NULL: all 1, and then bit-identical to ssi_ce_fwd): row_loss[r] = w[r] (lse - logit[label]), gradient row
+ * w[r] (softmax - onehot); w >= 0.  The reference normalises every micro-batch of an accumulation window by ITS OWN count of shifted labels and
+ * weights it by its own count of unshifted ones (ssi/trainer.py:385-395 with ssi/loss.py:16-22); a window that runs as one batch carries that
+ * ratio per row here.  In the register-resident bf16 kernel the weight is an additive term of the exponent: no cost per element. */
+int ssi_ce_fwd_weighted(void* logits, int64_t ld, const int64_t* labels, const float* row_weight, int64_t rows, int64_t vocab,
+                        int64_t ignore_index, float* row_loss, float* row_lse, int write_grad, int dtype, void* stream);
 
 /* ---- K8 + K9 as one entry per direction: tied LM head (TiedLinear over tok_embeddings, ssi/loss.py:8-14) + chunked CE (trainer.py:300) ----
  * fwd: logits_ws[rows, vocab_pad] = hidden[rows, dim] table[vocab_pad, dim]^T (table rows >= vocab are zero padding), then ssi_ce_fwd

@@ -191,7 +191,7 @@ extern "C" int ssi_embed_bwd(const int64_t* tokens, const void* dout, void* dtab
 template <typename T>
 __global__ __launch_bounds__(512) void ce_fwd_kernel(T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
                                                      int64_t vocab, int64_t ignore_index, float* __restrict__ row_loss,
-                                                     float* __restrict__ row_lse, int write_grad) {
+                                                     float* __restrict__ row_lse, int write_grad, const float* __restrict__ row_weight) {
     constexpr int N = Vec16<T>::N;
     __shared__ float red[16];
     const int64_t row = blockIdx.x;
@@ -223,8 +223,9 @@ __global__ __launch_bounds__(512) void ce_fwd_kernel(T* __restrict__ logits, int
     s = (m == -INFINITY) ? 0.f : s * expf(m - gm);
     const float gs = block_sum(s, red);
     const float lse = gm + logf(gs);
+    const float w = row_weight ? row_weight[row] : 1.f;  // weighted rows (ssi_ce_fwd_weighted): loss and gradient of the row times w
     if (threadIdx.x == 0) {
-        row_loss[row] = lse - to_f32<T>(lr[label]);
+        row_loss[row] = w * (lse - to_f32<T>(lr[label]));
         if (row_lse) row_lse[row] = lse;
     }
     if (!write_grad) return;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(512) void ce_fwd_kernel(T* __restrict__ logits, int
         for (int i = 0; i < N; ++i) {
             const int64_t c = v * N + i;
             float g = 0.f;
-            if (c < vocab) g = expf(a.get(i) - lse) - (c == label ? 1.f : 0.f);
+            if (c < vocab) g = w * (expf(a.get(i) - lse) - (c == label ? 1.f : 0.f));
             o.set(i, g);
         }
         store16(lr + v * N, o);
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(512) void ce_fwd_kernel(T* __restrict__ logits, int
 template <int NCH, bool write_grad>
 __global__ __launch_bounds__(1024, 4) void ce_row_bf16_kernel(bf16_t* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
                                                               int64_t rows, int64_t vocab, int64_t ignore_index,
-                                                              float* __restrict__ row_loss, float* __restrict__ row_lse) {
+                                                              float* __restrict__ row_loss, float* __restrict__ row_lse,
+                                                              const float* __restrict__ row_weight) {
     __shared__ float red[16];
     constexpr float LOG2E = 1.44269504088896340736f;
     constexpr int CHUNK = 8192;                      // columns per chunk: 1024 threads x 8 bf16
@@ -285,6 +287,10 @@ __global__ __launch_bounds__(1024, 4) void ce_row_bf16_kernel(bf16_t* __restrict
         const int64_t next = row + gridDim.x;
         const int64_t label = labels[row];
         const bool valid = is_valid(label);
+        // a weighted row (ssi_ce_fwd_weighted): w * exp(x - lse) = exp2(x log2e - lse log2e + log2 w) — the weight rides in the exponent's
+        // additive term at no cost per element; w = 1 (and no weights) adds an exact 0
+        const float w = row_weight ? row_weight[row] : 1.f;
+        const float log2w = row_weight ? __log2f(w) : 0.f;
         const __amdgpu_buffer_rsrc_t rs = rsrc_of(row);
         // columns that are not vocabulary (the pad columns [vocab, ld), and beyond the row where the loads returned 0) become -inf
         // once, in the registers: max, exp-sum and gradient (exp2(-inf) = 0) then need no column test at all
@@ -321,10 +327,10 @@ __global__ __launch_bounds__(1024, 4) void ce_row_bf16_kernel(bf16_t* __restrict
             const float gs = block_sum(s, red);
             const float lse = gm + logf(gs);
             if (tid == 0) {
-                row_loss[row] = lse - xl;
+                row_loss[row] = w * (lse - xl);
                 if (row_lse) row_lse[row] = lse;
             }
-            nl = -lse * LOG2E;
+            nl = -lse * LOG2E + log2w;
         } else if (tid == 0) {
             row_loss[row] = 0.f;
             if (row_lse) row_lse[row] = 0.f;
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(1024, 4) void ce_row_bf16_kernel(bf16_t* __restrict
                 const int h = hot - c * CHUNK;
                 if ((unsigned)h < 8u) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) if (e == h) g[e] -= 1.f;
+                    for (int e = 0; e < 8; ++e) if (e == h) g[e] -= w;
                 }
                 bf16x8 ob;
 #pragma unroll
@@ -368,8 +374,8 @@ static int ce_num_cus() {
     return n;
 }
 
-extern "C" int ssi_ce_fwd(void* logits, int64_t ld, const int64_t* labels, int64_t rows, int64_t vocab,
-                          int64_t ignore_index, float* row_loss, float* row_lse, int write_grad, int dtype, void* stream) {
+extern "C" int ssi_ce_fwd_weighted(void* logits, int64_t ld, const int64_t* labels, const float* row_weight, int64_t rows, int64_t vocab,
+                                   int64_t ignore_index, float* row_loss, float* row_lse, int write_grad, int dtype, void* stream) {
     SSI_CHECK_ARG(logits && labels && row_loss && rows >= 0 && vocab > 0 && ld >= vocab && ld % 8 == 0);
     if (rows == 0) return SSI_OK;
     const int64_t chunks = ssi_cdiv(ld, 8192);
@@ -380,9 +386,9 @@ extern "C" int ssi_ce_fwd(void* logits, int64_t ld, const int64_t* labels, int64
 #define SSI_CE_ROW(N)                                                                                                                       \
     case N:                                                                                                                                 \
         if (write_grad) hipLaunchKernelGGL((ce_row_bf16_kernel<N, true>), grid, dim3(1024), 0, (hipStream_t)stream, (bf16_t*)logits, ld, labels, \
-                                           rows, vocab, ignore_index, row_loss, row_lse);                                                   \
+                                           rows, vocab, ignore_index, row_loss, row_lse, row_weight);                                       \
         else hipLaunchKernelGGL((ce_row_bf16_kernel<N, false>), grid, dim3(1024), 0, (hipStream_t)stream, (bf16_t*)logits, ld, labels, rows,     \
-                                vocab, ignore_index, row_loss, row_lse);                                                                    \
+                                vocab, ignore_index, row_loss, row_lse, row_weight);                                                        \
         break
         switch ((int)chunks) {
             SSI_CE_ROW(1); SSI_CE_ROW(2); SSI_CE_ROW(3); SSI_CE_ROW(4); SSI_CE_ROW(8); SSI_CE_ROW(16); SSI_CE_ROW(17); SSI_CE_ROW(18);
@@ -392,9 +398,14 @@ extern "C" int ssi_ce_fwd(void* logits, int64_t ld, const int64_t* labels, int64
         return SSI_OK;
     }
     SSI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(ce_fwd_kernel<T>, dim3((unsigned)rows), dim3(512), 0, (hipStream_t)stream,
-                                                 (T*)logits, ld, labels, vocab, ignore_index, row_loss, row_lse, write_grad));
+                                                 (T*)logits, ld, labels, vocab, ignore_index, row_loss, row_lse, write_grad, row_weight));
     SSI_LAUNCH_CHECK();
     return SSI_OK;
+}
+
+extern "C" int ssi_ce_fwd(void* logits, int64_t ld, const int64_t* labels, int64_t rows, int64_t vocab,
+                          int64_t ignore_index, float* row_loss, float* row_lse, int write_grad, int dtype, void* stream) {
+    return ssi_ce_fwd_weighted(logits, ld, labels, nullptr, rows, vocab, ignore_index, row_loss, row_lse, write_grad, dtype, stream);
 }
 
 // The valid-label count uses the predicate of the row kernels (not ignored AND inside [0, vocab)); labels that are neither ignored

@@ -20,7 +20,7 @@ SSI_F32, SSI_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_MFMA_WG8 = 0, 1, 2, 3
 TILES_STATIC, TILES_DYNAMIC = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 ATTN_KERNEL_DQ, ATTN_KERNEL_DKV = 0, 1
 ATTN_MODE_AUTO, ATTN_MODE_OLD, ATTN_MODE_NEW, ATTN_MODE_NO_HEAD_SPLIT = 0, 1, 2, 3
 ATTN_USED_DQ2, ATTN_USED_DKV2, ATTN_USED_HEAD_SPLIT, ATTN_USED_PLAN = 1, 2, 4, 8
@@ -73,6 +73,7 @@ PROTOTYPES = {
                                     _P]),
     "ssi_transpose": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int, _P]),
     "ssi_ce_fwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, c_int, c_int, _P]),
+    "ssi_ce_fwd_weighted": (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, c_int64, _P, _P, c_int, c_int, _P]),
     "ssi_ce_reduce": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P]),
     "ssi_lmhead_ce_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P, _P, c_int, c_int, _P]),
     "ssi_lmhead_ce_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, _P]),

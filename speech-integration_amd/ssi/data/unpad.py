@@ -88,4 +88,6 @@ def loss_inputs(batch: dict[str, Any]) -> dict[str, Any]:
     out = {"tokens": batch["packed_tokens"], "labels": batch["packed_labels"], "input_pos": batch["packed_input_pos"]}
     if batch.get(PLAN_KEY) is not None:
         out["attn_plan"] = batch[PLAN_KEY]
+    if batch.get("packed_loss_weights") is not None:  # a window's micro-batches joined (ssi/data/window.py)
+        out["loss_weights"] = batch["packed_loss_weights"]
     return out

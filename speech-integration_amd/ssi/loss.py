@@ -70,9 +70,14 @@ def compute_loss(batch: dict[str, Tensor], model, loss_fn: Callable) -> Tensor:
     if (hasattr(model, "fused_loss") and isinstance(loss_fn, CEWithChunkedOutputLoss) and batch.get("encoder_input") is None
             and (batch.get("mask") is None or batch.get("input_pos") is not None)):
         # packed batches (ssi/data/packed.py) carry input_pos: block-causal attention, per-document RoPE positions
+        extra = {}
         if batch.get("attn_plan") is not None:  # made on the host beside a packed batch (ssi/attn_plan.py): pipelined attention backward
-            return model.fused_loss(batch["tokens"], labels, ignore_index, input_pos=batch.get("input_pos"), attn_plan=batch["attn_plan"])
-        return model.fused_loss(batch["tokens"], labels, ignore_index, input_pos=batch.get("input_pos"))
+            extra["attn_plan"] = batch["attn_plan"]
+        if batch.get("loss_weights") is not None:  # an accumulation window run as one batch (ssi/data/window.py): weights per SHIFTED label
+            extra["loss_weights"] = batch["loss_weights"]
+        return model.fused_loss(batch["tokens"], labels, ignore_index, input_pos=batch.get("input_pos"), **extra)
+    if batch.get("loss_weights") is not None:
+        raise ValueError("loss_weights need the fused LM head + cross-entropy of the HIP decoder (model.fused_loss)")
     logits = model(
         tokens=batch["tokens"],
         mask=batch.get("mask"),

@@ -751,36 +751,46 @@ class HipLlamaDecoder(nn.Module):
         return logits.float()
 
     def fused_loss(self, tokens: Tensor, shifted_labels: Tensor, ignore_index: int = CROSS_ENTROPY_IGNORE_IDX,
-                   input_pos: Optional[Tensor] = None, attn_plan=None) -> Tensor:
+                   input_pos: Optional[Tensor] = None, attn_plan=None, loss_weights: Optional[Tensor] = None) -> Tensor:
         """Mean NLL over non-ignored (already shifted) labels with the LM head + CE fused: equals
         ``CEWithChunkedOutputLoss()(model(tokens, input_pos=...), shifted_labels)`` of the reference for any chunk count.
         ``input_pos`` ([B, S], restarting at 0 with every document): packed rows, block-causal attention.  ``attn_plan``
         (``build_attn_plan(input_pos)`` made on the host beside the batch): the attention backward then runs its pipelined kernels on the
-        packed rows; without one (and with ``input_pos`` on the device) the round-1..3 kernels run — same results to rounding."""
+        packed rows; without one (and with ``input_pos`` on the device) the round-1..3 kernels run — same results to rounding.
+        ``loss_weights`` (fp32 ``[B, S]``, >= 0, aligned with ``shifted_labels``): the result is ``sum_i w_i nll_i / n_valid`` — how an
+        accumulation window that runs as one batch keeps the reference's per-micro-batch normalisation (``ssi/data/window.py``)."""
         tokens = self._check_inputs(tokens, None, None, None, input_pos)
         B, S = tokens.shape
+        if loss_weights is not None:
+            if loss_weights.shape != tokens.shape:
+                raise ValueError(f"loss_weights {tuple(loss_weights.shape)} vs tokens {tuple(tokens.shape)}")
+            loss_weights = loss_weights.to(device=tokens.device, dtype=torch.float32)
         Sp = self.padded_seq_len(B, S)
         if Sp != S:
             pad_t = torch.zeros(B, Sp - S, dtype=tokens.dtype, device=tokens.device)
             tokens = torch.cat([tokens, pad_t], dim=1)
             shifted_labels = torch.cat([shifted_labels, torch.full_like(pad_t, ignore_index)], dim=1)
+            if loss_weights is not None:
+                loss_weights = torch.cat([loss_weights, torch.ones(B, Sp - S, dtype=torch.float32, device=tokens.device)], dim=1)
             if input_pos is not None:  # the tail continues the last document (as PackedDataset pads a pack)
                 cont = input_pos[:, -1:].to(tokens.device) + torch.arange(1, Sp - S + 1, device=tokens.device)
                 input_pos = torch.cat([input_pos.to(tokens.device), cont.clamp_(max=self._rope.shape[0] - 1)], dim=1)
         labels = shifted_labels.reshape(-1).contiguous()
+        weights = None if loss_weights is None else loss_weights.reshape(-1).contiguous()
         if torch.is_grad_enabled() and self.training:
-            return _FusedLossFn.apply(self, tokens, labels, ignore_index, self._anchor, input_pos, attn_plan)
+            return _FusedLossFn.apply(self, tokens, labels, ignore_index, self._anchor, input_pos, attn_plan, weights)
         hn = self._forward_hidden(tokens, save=False, input_pos=input_pos)
-        return self._ce_forward(hn, labels, ignore_index, write_grad=False)[0]
+        return self._ce_forward(hn, labels, ignore_index, write_grad=False, weights=weights)[0]
 
-    def _ce_forward(self, hn: Tensor, labels: Tensor, ignore_index: int, write_grad: bool) -> tuple[Tensor, Tensor, Tensor]:
+    def _ce_forward(self, hn: Tensor, labels: Tensor, ignore_index: int, write_grad: bool,
+                    weights: Optional[Tensor] = None) -> tuple[Tensor, Tensor, Tensor]:
         """Tied head + cross-entropy: (mean loss, stats, logits buffer — which holds softmax - onehot when ``write_grad``).  The same
         three launches as the one-call ABI entry ``ssi_lmhead_ce_fwd`` (``ops.lmhead_ce_fwd``), issued one by one here so that ``bench.py``
         can time the head GEMM on its own."""
         T = hn.shape[0]
         logits = self._head_logits(hn, "logits" if write_grad else "logits.x")
         row_loss = self._arena.get("row_loss" if write_grad else "row_loss.x", (T,), torch.float32)
-        ops.ce_fwd(logits, labels, self.vocab_size, ignore_index, row_loss, None, write_grad)
+        ops.ce_fwd(logits, labels, self.vocab_size, ignore_index, row_loss, None, write_grad, row_weight=weights)
         out = torch.empty(4, dtype=torch.float32, device=self.device)
         ops.ce_reduce(row_loss, labels, self.vocab_size, ignore_index, out)
         self.label_errors = out[3]  # device scalar: labels outside [0, vocab); the trainer folds it into its one read-back and raises
@@ -823,9 +833,9 @@ class _FusedLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model: HipLlamaDecoder, tokens: Tensor, labels: Tensor, ignore_index: int, anchor: Tensor,
-                input_pos: Optional[Tensor] = None, attn_plan=None) -> Tensor:
+                input_pos: Optional[Tensor] = None, attn_plan=None, weights: Optional[Tensor] = None) -> Tensor:
         hn = model._forward_hidden(tokens, save=True, input_pos=input_pos, attn_plan=attn_plan)
-        loss, stats, dlogits = model._ce_forward(hn, labels, ignore_index, write_grad=True)
+        loss, stats, dlogits = model._ce_forward(hn, labels, ignore_index, write_grad=True, weights=weights)
         ctx.model, ctx.gen = model, model._fwd_generation
         ctx.save_for_backward(hn, stats, dlogits)
         return loss.clone()
@@ -841,7 +851,7 @@ class _FusedLossFn(torch.autograd.Function):
         alpha = (grad_out.to(torch.float32).reshape(1) / stats[2:3]).contiguous()
         d_hn = m._head_backward(dlogits, hn, alpha)
         m._backward_hidden(d_hn, ctx.gen)
-        return None, None, None, None, torch.zeros_like(m._anchor), None, None
+        return None, None, None, None, torch.zeros_like(m._anchor), None, None, None
 
 
 # --------------------------------------------------------------------------------------------------------------------

@@ -314,12 +314,18 @@ def transpose(src: Tensor, dst: Tensor) -> None:
 
 
 def ce_fwd(logits: Tensor, labels: Tensor, vocab: int, ignore_index: int, row_loss: Tensor, row_lse: Tensor | None,
-           write_grad: bool) -> None:
+           write_grad: bool, row_weight: Tensor | None = None) -> None:
+    """``row_weight`` (fp32, one per row, >= 0; ``ssi_ce_fwd_weighted``): loss and gradient of row r times ``row_weight[r]``."""
     assert logits.dim() == 2 and logits.stride(1) == 1 and labels.dtype == torch.int64 and labels.is_contiguous()
     rows = logits.shape[0]
     assert labels.numel() == rows and row_loss.dtype == torch.float32 and row_loss.numel() >= rows
-    check(_lib.load().ssi_ce_fwd(ptr(logits), logits.stride(0), ptr(labels), rows, vocab, ignore_index, ptr(row_loss),
-                                 ptr(row_lse), int(write_grad), dtype_code(logits.dtype), stream_ptr()), "ssi_ce_fwd")
+    if row_weight is None:
+        check(_lib.load().ssi_ce_fwd(ptr(logits), logits.stride(0), ptr(labels), rows, vocab, ignore_index, ptr(row_loss),
+                                     ptr(row_lse), int(write_grad), dtype_code(logits.dtype), stream_ptr()), "ssi_ce_fwd")
+        return
+    assert row_weight.dtype == torch.float32 and row_weight.is_contiguous() and row_weight.numel() == rows and row_weight.device == logits.device
+    check(_lib.load().ssi_ce_fwd_weighted(ptr(logits), logits.stride(0), ptr(labels), ptr(row_weight), rows, vocab, ignore_index, ptr(row_loss),
+                                          ptr(row_lse), int(write_grad), dtype_code(logits.dtype), stream_ptr()), "ssi_ce_fwd_weighted")
 
 
 def ce_reduce(row_loss: Tensor, labels: Tensor, vocab: int, ignore_index: int, out: Tensor) -> None:

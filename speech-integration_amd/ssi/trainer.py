@@ -123,7 +123,7 @@ class Trainer:
                         "grad_sync", "_grad_norm", "_loss_log", "_resume_state", "_resume_rng_state")
     _COUNTERS = {"rank": 0, "global_step": 0, "consumed_samples": 0, "tokens_train_total": 0, "wall_clock_offset": 0.0,
                  "loss_running": 0.0, "num_tokens_step": 0, "max_seq_len_step": 0, "t_train_start": 0.0, "t_step_start": 0.0,
-                 "unpadded_micro_batches": 0}
+                 "unpadded_micro_batches": 0, "fused_micro_batches": 0}
 
     def __init__(self, cfg) -> None:
         self.cfg = cfg
@@ -341,18 +341,36 @@ class Trainer:
     def _epoch_batches(self, epoch: int, batches_to_skip: int):
         """``(index, batch)`` pairs of one epoch: the first ``usable_batches`` of the loader (whole accumulation windows only), minus
         the ones a resumed run has already consumed.  Sampler and dataset are told the epoch (shuffling and the per-sample generators
-        of the CPT data key on it); batches are collated, pinned and copied to the device ahead of the step by a background thread."""
+        of the CPT data key on it); batches are collated, stripped of their padding, pinned and copied to the device ahead of the step by a
+        background thread.  With ``gradient_accumulation_steps > 1`` the micro-batches of a window arrive joined into one batch where they can be
+        (``ssi.data.window``): the index is then that of the window's LAST micro-batch."""
         for obj in (self.sampler_train, getattr(self.data_train, "dataset", None)):
             if obj is not None and hasattr(obj, "set_epoch"):
                 obj.set_epoch(epoch)
-        source = self.data_train
-        depth = int(self.cfg.get("prefetch_batches", 2) or 0)
-        if self.device.type == "cuda" and depth > 0:
-            from .data.prefetch import DevicePrefetcher
-            source = DevicePrefetcher(self.data_train, self.device, depth=depth, transform=self._host_batch_transform())
         if batches_to_skip:
             LOGGER.info(f"resume: epoch {epoch} starts at batch {batches_to_skip}")
-        return itertools.islice(enumerate(source), batches_to_skip, self.geometry.usable_batches)
+        indexed = itertools.islice(enumerate(self.data_train), batches_to_skip, self.geometry.usable_batches)
+        transform = self._host_batch_transform()
+        window = int(self.cfg.gradient_accumulation_steps)
+        if transform is not None and window > 1 and self.cfg.get("fuse_accumulation_window", True):
+            from .data.window import fused_windows
+            kw = transform.keywords
+            indexed = fused_windows(indexed, window, max_tokens=int(self.cfg.get("fused_window_max_tokens", 32768)), single=transform,
+                                    pad_id=kw["pad_id"], ignore_index=kw["ignore_index"], multiple=kw["multiple"], plan_fn=kw["plan_fn"])
+        elif transform is not None:
+            indexed = ((i, transform(b)) for i, b in indexed)
+        depth = int(self.cfg.get("prefetch_batches", 2) or 0)
+        if self.device.type != "cuda" or depth <= 0:
+            return indexed
+        from .data.prefetch import DevicePrefetcher
+
+        def tagged():  # the prefetcher moves dictionaries; the index rides along as a plain value
+            for i, b in indexed:
+                b = dict(b)
+                b["_index"] = i
+                yield b
+
+        return ((b.pop("_index"), b) for b in DevicePrefetcher(tagged(), self.device, depth=depth))
 
     def _host_batch_transform(self):
         """Right-padded batches lose their padding on the host, in the prefetch thread (``ssi.data.unpad``: exact, and the step's time then follows
@@ -384,7 +402,7 @@ class Trainer:
         batch_to_device(batch, self.device)
         tokens, labels = batch["tokens"], batch["labels"]
         ignore = self.loss_fn.ignore_index
-        self.max_seq_len_step = max(self.max_seq_len_step, tokens.size(1))
+        self.max_seq_len_step = max(self.max_seq_len_step, int(batch.get("max_seq_len", tokens.size(1))))
         on_gpu = tokens.is_cuda
         if on_gpu:  # K14: ranges + non-pad + valid labels in one launch, result stays on the device
             counts_dev = count_token_types_async(tokens, self.token_type_ranges, self.tokenizer.pad_id, labels, ignore)
@@ -396,7 +414,9 @@ class Trainer:
             self.model.sync_this_backward = bool(sync_gradients)
         if on_gpu:
             self._arm_optimizer(n_valid, bool(sync_gradients))
-        self.unpadded_micro_batches += "packed_tokens" in batch  # (the prefetch thread dropped this batch's padding: ssi/data/unpad.py)
+        if "packed_tokens" in batch:  # the prefetch thread dropped this batch's padding (ssi/data/unpad.py) or joined a window's micro-batches
+            self.unpadded_micro_batches += int(batch.get("micro_batches", 1))
+            self.fused_micro_batches += int(batch.get("micro_batches", 0))
         loss_batch = compute_loss(loss_inputs(batch), self.model, self.loss_fn) * n_valid  # mean over SHIFTED x UNSHIFTED count
         loss_batch.backward()
         if on_gpu:

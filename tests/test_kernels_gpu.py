@@ -209,6 +209,44 @@ def test_cross_entropy_register_resident_rows_many_rows_per_workgroup(ops):
     assert float((f32.cpu() - grad).abs().max()) <= 4e-3
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("vocab,ld", [(515, 520), (133_258, 133_376), (20_000, 20_480)])
+def test_cross_entropy_with_a_weight_per_row(ops, dtype, vocab, ld):
+    """``ssi_ce_fwd_weighted`` (ABI v8; an accumulation window run as one batch, ``ssi/data/window.py``): loss and gradient of row r times
+    w[r], against fp32 torch; weights of exactly 1 give the bits of the unweighted call, a weight of 0 a zero row.  Both kernels: the
+    register-resident bf16 one (the weight rides in the exponent) and the 3-pass one."""
+    rows = 300
+    logits = rnd(rows, ld, dtype=dtype, seed=31, scale=3.0)
+    g = torch.Generator().manual_seed(32)
+    labels = torch.randint(0, vocab, (rows,), generator=g)
+    labels[::9] = -100
+    w = 0.97 + 0.06 * torch.rand(rows, generator=g)        # (the real ones differ from 1 by a few 1e-4)
+    w[5], w[6], w[7] = 0.0, 1.0, 2.5
+    lr = logits[:, :vocab].float().clone().requires_grad_(True)
+    nll = F.cross_entropy(lr, labels, ignore_index=-100, reduction="none")
+    (w * nll).sum().backward()
+    work = logits.to(DEV)
+    row_loss = torch.empty(rows, dtype=torch.float32, device=DEV)
+    ops.ce_fwd(work, labels.to(DEV), vocab, -100, row_loss, None, True, row_weight=w.to(DEV))
+    torch.testing.assert_close(row_loss.cpu(), (w * nll).detach(), rtol=2e-5, atol=2e-5)
+    grad = work.cpu().float()
+    torch.testing.assert_close(grad[:, :vocab], lr.grad, rtol=2e-5 if dtype == torch.float32 else 1e-2, atol=1e-6 if dtype == torch.float32 else 4e-3)
+    assert (grad[:, vocab:] == 0).all() and (grad[labels == -100] == 0).all() and (grad[5] == 0).all() and float(row_loss[5]) == 0.0
+    out = torch.empty(4, dtype=torch.float32, device=DEV)
+    ops.ce_reduce(row_loss, labels.to(DEV), vocab, -100, out)
+    n_valid = int((labels != -100).sum())
+    assert out.cpu()[2].item() == n_valid and out.cpu()[0].item() == pytest.approx(float((w * nll).sum()) / n_valid, rel=2e-5)
+    # the weighted sum of the exact (unrounded) gradient rows is what matters downstream: relative error of the row sums of |grad|
+    plain, ones = logits.to(DEV), logits.to(DEV)
+    rl_plain, rl_ones = torch.empty_like(row_loss), torch.empty_like(row_loss)
+    ops.ce_fwd(plain, labels.to(DEV), vocab, -100, rl_plain, None, True)
+    ops.ce_fwd(ones, labels.to(DEV), vocab, -100, rl_ones, None, True, row_weight=torch.ones(rows, device=DEV))
+    assert torch.equal(plain, ones) and torch.equal(rl_plain, rl_ones), "weights of 1 must change no bit"
+    assert torch.equal(work[6], plain[6]) and float(row_loss[6]) == float(rl_plain[6])
+    with pytest.raises(AssertionError):
+        ops.ce_fwd(work, labels.to(DEV), vocab, -100, row_loss, None, True, row_weight=torch.ones(rows - 1, device=DEV))
+
+
 def test_count_tokens_matches_reference_counts(ops):
     from oracle.step_oracle import count_token_types, token_type_ranges
     from ssi.train_utils import count_token_types as ct_gpu, count_token_types_async

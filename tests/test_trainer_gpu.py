@@ -25,7 +25,7 @@ class _Remap:
     """The synthetic generator draws ids from the production vocabulary layout; fold them into the shrunken test vocabulary."""
 
     def __init__(self, loader, vocab):
-        self.loader, self.dataset, self.vocab = loader, loader.dataset, vocab
+        self.loader, self.dataset, self.vocab, self.label_first = loader, loader.dataset, vocab, False
 
     def __len__(self):
         return len(self.loader)
@@ -33,7 +33,10 @@ class _Remap:
     def __iter__(self):
         for b in self.loader:
             tok = b["tokens"] % self.vocab
-            yield {"tokens": tok, "labels": torch.where(b["labels"] == -100, b["labels"], tok)}
+            labels = torch.where(b["labels"] == -100, b["labels"], tok)
+            if self.label_first:  # the reference's CPT rows: labels = tokens, column 0 included (/root/reference/ssi/data/cpt.py:153)
+                labels[:, 0] = tok[:, 0]
+            yield {"tokens": tok, "labels": labels}
 
 
 def _trainer(tmp, name, config_name="sft", dtype="fp32", overrides=(), model=SMALL, seq=96):
@@ -224,6 +227,41 @@ def test_adamw_under_the_backward_changes_no_bit(tmp_path, dtype, model):
     clip.optimizer.overlap_with_backward = lambda s: (_ for _ in ()).throw(AssertionError("armed although gradients are clipped"))
     clip.train()
     clip.cleanup()
+
+
+@pytest.mark.parametrize("config_name,dtype,model", [("sft", "fp32", SMALL), ("cpt", "fp32", SMALL), ("cpt", "bf16", MFMA_SMALL)])
+def test_a_window_run_as_one_batch_is_the_micro_batch_loop(tmp_path, config_name, dtype, model):
+    """Round 5 (``fuse_accumulation_window``, default on; ``ssi/data/window.py``): the micro-batches of an accumulation window reach the model
+    as ONE packed batch.  The reference's loop (``trainer.py:385-424``) normalises each micro-batch by its own count of shifted labels and
+    weights it by its own count of unshifted ones; the joined batch keeps that per token (``ssi_ce_fwd_weighted``) — the CPT rows, ragged
+    with every token a label, are the case where the ratios differ, the SFT rows (BOS masked) the one where no weights are needed.  6
+    optimizer steps of 3 micro-batches through ``Trainer.train()`` with the switch on and off: same counters, losses and final weights equal
+    up to the summation order (fp32) / the rounding of the gradient accumulator (bf16: the joined window rounds once where the loop rounds
+    after every micro-batch)."""
+    seq = 96 if dtype == "fp32" else 128
+    runs = {}
+    for name, extra in (("joined", []), ("loop", ["fuse_accumulation_window=false"])):
+        t = _trainer(tmp_path, name, config_name=config_name, dtype=dtype, model=model, seq=seq,
+                     overrides=["max_steps=6", "gradient_accumulation_steps=3", "data.train.dataset.n_samples=36",
+                                "data.train.dataset.fixed_len=false", *extra])
+        t.data_train.label_first = config_name == "cpt"
+        weighted, real = [], t.model.fused_loss
+        t.model.fused_loss = lambda *a, real=real, weighted=weighted, **k: (weighted.append(k.get("loss_weights") is not None), real(*a, **k))[1]
+        t.train()
+        runs[name] = dict(losses=list(t._loss_log), w={k: v.detach().float().clone() for k, v in t.model.state_dict().items()}, calls=list(weighted),
+                          joined=t.fused_micro_batches, tokens=t.tokens_train_total, counts=dict(t.token_type_counts_total),
+                          consumed=t.consumed_samples, step=t.global_step, max_seq=t.max_seq_len_step)
+        t.cleanup()
+        del t
+    a, b = runs["joined"], runs["loop"]
+    assert a["joined"] == 18 and b["joined"] == 0 and len(a["calls"]) == 6 and len(b["calls"]) == 18 and not any(b["calls"])
+    assert all(a["calls"]) if config_name == "cpt" else not any(a["calls"])
+    for k in ("tokens", "counts", "consumed", "step"):
+        assert a[k] == b[k], k
+    tol = 2e-6 if dtype == "fp32" else 3e-3
+    assert len(set(a["losses"])) == 6 and all(abs(x - y) <= tol * abs(y) for x, y in zip(a["losses"], b["losses"])), (a["losses"], b["losses"])
+    worst = max(float((a["w"][k] - b["w"][k]).abs().max()) for k in a["w"])
+    assert worst <= (2e-3 if dtype == "fp32" else 6e-2), worst   # (lr 2e-2 x 6 steps: AdamW moves every weight by up to 0.12)
 
 
 def test_adamw_under_the_backward_skips_a_window_without_labels():
