@@ -262,7 +262,9 @@ def through_trainer(args, result_out) -> int:
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
     runs = {}
-    for ga in (1, 4):
+    # grad-accum 4 twice: the window as ONE packed batch (the trainer's default, ssi/data/window.py) and as the reference's micro-batch loop
+    for ga, joined in ((1, True), (4, True), (4, False)):
+        key = f"grad_accum_{ga}" + ("" if joined else "_micro_batch_loop")
         tmp = tempfile.mkdtemp(prefix="ssi_through_trainer_")
         steps = args.warmup + args.steps
         cfg = compose(os.path.join(PKG, "conf"), "sft", [
@@ -270,7 +272,8 @@ def through_trainer(args, result_out) -> int:
             f"tokenizer.max_seq_len={args.seq}", f"data.train.dataset.n_samples={steps * ga * args.batch}", "data.dev.dataset.n_samples=8",
             f"data.train.dataloader.batch_size={args.batch}", "eval_steps=1000000000", "save_steps=1000000000", f"output_dir={tmp}",
             f"checkpointer.output_dir={tmp}/ckpt", f"checkpointer.checkpoint_dir={tmp}/none", "checkpointer.allow_random_init=true",
-            f"speech.n_dsus={args.n_dsus}"] + (["data.train.dataset.fixed_len=false"] if args.padded else []))
+            f"speech.n_dsus={args.n_dsus}", f"fuse_accumulation_window={'true' if joined else 'false'}"]
+            + (["data.train.dataset.fixed_len=false"] if args.padded else []))
         resolve_n_dsus(cfg)
         t = Trainer(cfg)
         t.setup()
@@ -282,15 +285,16 @@ def through_trainer(args, result_out) -> int:
         rec = t.wandb_logger.records[args.warmup:]
         assert len(rec) == args.steps and t.global_step == steps
         dur = [r["duration_step"] for r in rec]
-        runs[f"grad_accum_{ga}"] = {
+        runs[key] = {
             "tokens_per_second_per_gpu": sum(r["tokens_per_second_per_gpu"] for r in rec) / len(rec),
             "positions_per_second": sum(ga * args.batch * args.seq / d for d in dur) / len(dur),
             "ms_per_optimizer_step": 1e3 * sum(dur) / len(dur), "ms_per_micro_batch": 1e3 * sum(dur) / len(dur) / ga,
-            "steps": len(rec), "warmup": args.warmup, "train_wall_s": wall, "last_loss": rec[-1]["loss"]}
+            "steps": len(rec), "warmup": args.warmup, "train_wall_s": wall, "last_loss": rec[-1]["loss"],
+            "micro_batches_joined_into_one_batch_per_window": t.fused_micro_batches}
         if args.padded:  # ragged rows: the prefetch thread dropped the padding and built the attention backward's work plan beside each batch
             from ssi import _lib as _l, ops as _o
             used = _o.attn_last_dispatch()
-            runs[f"grad_accum_{ga}"].update({
+            runs[key].update({
                 "micro_batches_run_without_their_padding": t.unpadded_micro_batches,
                 "attention_backward_of_the_last_micro_batch": {"dq2": bool(used & _l.ATTN_USED_DQ2), "dkv2": bool(used & _l.ATTN_USED_DKV2),
                                                                "work_plan": bool(used & _l.ATTN_USED_PLAN), "head_split": bool(used & _l.ATTN_USED_HEAD_SPLIT)}})
