@@ -85,7 +85,9 @@ def loss_inputs(batch: dict[str, Any]) -> dict[str, Any]:
     """What ``compute_loss`` should see: the packed copy when the prefetcher made one, the batch itself otherwise."""
     if PACKED_KEYS[0] not in batch:
         return batch
-    out = {"tokens": batch["packed_tokens"], "labels": batch["packed_labels"], "input_pos": batch["packed_input_pos"]}
+    out = {"tokens": batch["packed_tokens"], "labels": batch["packed_labels"]}
+    if batch.get("packed_input_pos") is not None:  # (absent: a window's full rows stacked as plain rows, ssi/data/window.py)
+        out["input_pos"] = batch["packed_input_pos"]
     if batch.get(PLAN_KEY) is not None:
         out["attn_plan"] = batch[PLAN_KEY]
     if batch.get("packed_loss_weights") is not None:  # a window's micro-batches joined (ssi/data/window.py)

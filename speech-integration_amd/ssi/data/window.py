@@ -52,12 +52,16 @@ def kept_lengths(labels: torch.Tensor, ignore_index: int) -> torch.Tensor:
 
 
 def fuse_micro_batches(batches: list[dict[str, Any]], *, pad_id: int = 0, ignore_index: int = CROSS_ENTROPY_IGNORE_IDX, multiple: int = 256,
-                       plan_fn: Optional[Callable[[torch.Tensor], Any]] = None) -> Optional[dict[str, Any]]:
+                       plan_fn: Optional[Callable[[torch.Tensor], Any]] = None, padded_len: Optional[Callable[[int, int], int]] = None,
+                       min_saving: float = 0.03) -> Optional[dict[str, Any]]:
     """One batch for ``len(batches) >= 2`` consecutive micro-batches of a window, or ``None`` when they cannot be fused (see the module text).
     The result has the keys of an unpadded batch (``ssi.data.unpad``): ``tokens`` / ``labels`` — here the micro-batches' own tensors flattened
     and joined, ``[1, sum B_m S_m]``, which is all the trainer's counts need (they are sums over elements) — the packed copy the model runs,
     ``packed_loss_weights`` when the micro-batches' ratios differ, the attention backward's plan, ``max_seq_len`` (the widest micro-batch)
-    and ``micro_batches``."""
+    and ``micro_batches``.  Micro-batches of one width whose rows are (nearly) full — dropping the padding would save less than ``min_saving`` of
+    the rows the model runs, ``padded_len(B, S)`` per sequence — are stacked as plain rows ``[sum B_m, S]`` instead: no ``packed_input_pos``,
+    the model's plain causal path (the headline's kernels), labels untouched (a row's column 0 is never a target, its last position's target
+    is ignored by the shift)."""
     if len(batches) < 2 or not all(_plain_padded(b) for b in batches):
         return None
     u = [int((b["labels"] != ignore_index).sum()) for b in batches]
@@ -70,6 +74,22 @@ def fuse_micro_batches(batches: list[dict[str, Any]], *, pad_id: int = 0, ignore
     U, S = sum(u), sum(s)
     uniform = all(u[m] * s[0] == u[0] * s[m] for m in range(len(batches)))
     tok_dtype, lab_dtype = batches[0]["tokens"].dtype, batches[0]["labels"].dtype
+    counted = {"tokens": torch.cat([b["tokens"].reshape(1, -1) for b in batches], dim=1),
+               "labels": torch.cat([b["labels"].reshape(1, -1) for b in batches], dim=1),
+               "max_seq_len": max(int(b["tokens"].shape[1]) for b in batches), "micro_batches": len(batches)}
+    widths = {int(b["tokens"].shape[1]) for b in batches}
+    if len(widths) == 1:
+        (width,) = widths
+        n_rows = sum(int(b["tokens"].shape[0]) for b in batches)
+        rows_now = n_rows * (padded_len(n_rows, width) if padded_len is not None else width)
+        if t_packed > (1.0 - min_saving) * rows_now:  # nothing to gain from dropping the padding: plain rows
+            out = dict(counted)
+            out["packed_tokens"] = torch.cat([b["tokens"] for b in batches], dim=0)
+            out["packed_labels"] = torch.cat([b["labels"] for b in batches], dim=0)
+            if not uniform:
+                out[WEIGHTS_KEY] = torch.cat([torch.full(b["tokens"].shape, (u[m] / s[m]) * (S / U), dtype=torch.float32)
+                                              for m, b in enumerate(batches)], dim=0)
+            return out
     p_tokens = torch.full((1, t_packed), int(pad_id), dtype=tok_dtype)
     p_labels = torch.full((1, t_packed), int(ignore_index), dtype=lab_dtype)
     p_pos = torch.empty((1, t_packed), dtype=torch.int64)
@@ -89,12 +109,7 @@ def fuse_micro_batches(batches: list[dict[str, Any]], *, pad_id: int = 0, ignore
                 p_w[0, o:o + n] = w_m
             o += n
     p_pos[0, o:] = torch.arange(t_packed - o, dtype=torch.int64)  # the tile tail: a document of its own, every label ignored
-    out: dict[str, Any] = {
-        "tokens": torch.cat([b["tokens"].reshape(1, -1) for b in batches], dim=1),
-        "labels": torch.cat([b["labels"].reshape(1, -1) for b in batches], dim=1),
-        "packed_tokens": p_tokens, "packed_labels": p_labels, "packed_input_pos": p_pos,
-        "max_seq_len": max(int(b["tokens"].shape[1]) for b in batches), "micro_batches": len(batches),
-    }
+    out: dict[str, Any] = {**counted, "packed_tokens": p_tokens, "packed_labels": p_labels, "packed_input_pos": p_pos}
     if p_w is not None:
         out[WEIGHTS_KEY] = p_w
     if plan_fn is not None:

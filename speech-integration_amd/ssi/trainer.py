@@ -356,7 +356,8 @@ class Trainer:
             from .data.window import fused_windows
             kw = transform.keywords
             indexed = fused_windows(indexed, window, max_tokens=int(self.cfg.get("fused_window_max_tokens", 32768)), single=transform,
-                                    pad_id=kw["pad_id"], ignore_index=kw["ignore_index"], multiple=kw["multiple"], plan_fn=kw["plan_fn"])
+                                    pad_id=kw["pad_id"], ignore_index=kw["ignore_index"], multiple=kw["multiple"], plan_fn=kw["plan_fn"],
+                                    padded_len=kw["padded_len"])
         elif transform is not None:
             indexed = ((i, transform(b)) for i, b in indexed)
         depth = int(self.cfg.get("prefetch_batches", 2) or 0)

@@ -69,8 +69,18 @@ def test_equal_ratios_need_no_weights_and_what_cannot_be_joined_is_declined():
     sft = [_ragged(2, 40, [40, 17], seed=1, prompt=3), _ragged(2, 33, [9, 33], seed=2, prompt=1)]   # column 0 masked: unshifted == shifted
     assert WEIGHTS_KEY not in fuse_micro_batches(sft, pad_id=PAD, multiple=16)
     cpt_fixed = [_ragged(4, 24, [24] * 4, seed=i) for i in range(4)]                               # equal counts: equal ratios
-    out = fuse_micro_batches(cpt_fixed, pad_id=PAD, multiple=16)
+    out = fuse_micro_batches(cpt_fixed, pad_id=PAD, multiple=16, min_saving=-1.0)                  # (forced to pack)
     assert WEIGHTS_KEY not in out and out["packed_tokens"].shape == (1, 384)
+    # full rows of one width: nothing to gain from packing — stacked as plain rows, the model's plain causal path
+    out = fuse_micro_batches(cpt_fixed, pad_id=PAD, multiple=16)
+    assert out["packed_tokens"].shape == (16, 24) and "packed_input_pos" not in out and WEIGHTS_KEY not in out and out["micro_batches"] == 4
+    assert torch.equal(out["packed_labels"], torch.cat([b["labels"] for b in cpt_fixed])) and out["tokens"].shape == (1, 384)
+    assert set(loss_inputs(out)) == {"tokens", "labels"}
+    assert "packed_input_pos" in fuse_micro_batches(cpt_fixed, pad_id=PAD, multiple=16, padded_len=lambda B, S: 32)   # the model would pad each row to 32
+    mixed = [cpt_fixed[0], _ragged(4, 24, [24] * 4, seed=9, prompt=2)]                             # ratios 24/23 and 1: weights, per row
+    out = fuse_micro_batches(mixed, pad_id=PAD, multiple=16)
+    w = out[WEIGHTS_KEY]
+    assert w.shape == (8, 24) and len(set(w[:4].flatten().tolist())) == 1 and len(set(w[4:].flatten().tolist())) == 1 and float(w[0, 0]) > float(w[4, 0])
     assert fuse_micro_batches(sft[:1], pad_id=PAD) is None                                         # one micro-batch: nothing to join
     empty = _ragged(2, 20, [20, 5], seed=5)
     empty["labels"][:, 1:] = -100
@@ -111,13 +121,15 @@ def test_a_stream_of_micro_batches_becomes_one_batch_per_window():
     assert all("packed_tokens" in b and "micro_batches" not in b for _, b in got)
 
 
-@pytest.mark.parametrize("kind", ["cpt_ragged", "sft"])
+@pytest.mark.parametrize("kind", ["cpt_ragged", "sft", "stacked"])
 def test_the_joined_window_has_the_running_loss_and_the_gradients_of_the_micro_batch_loop_on_the_cpu_oracle(kind):
     params, _, _, seed = hx.CASES["tiny"]
     sd = hx.seeded_state_dict(params, seed)
     V = params["vocab_size"]
     if kind == "cpt_ragged":   # every real token a label: unshifted - shifted = rows, the ratio differs from micro-batch to micro-batch
         mbs = [_ragged(2, 45, [45, 9], vocab=V, seed=3), _ragged(2, 30, [30, 28], vocab=V, seed=4), _ragged(2, 38, [12, 38], vocab=V, seed=5)]
+    elif kind == "stacked":    # full rows of one width stay plain rows; one micro-batch with masked prompts, one without: two ratios
+        mbs = [_ragged(2, 40, [40, 40], vocab=V, seed=3), _ragged(3, 40, [40, 40, 39], vocab=V, seed=4, prompt=3)]
     else:
         mbs = [_ragged(2, 45, [45, 9], vocab=V, seed=3, prompt=4), _ragged(2, 30, [30, 28], vocab=V, seed=4, prompt=2)]
     loss_fn = OracleCEWithChunkedOutputLoss()
@@ -130,10 +142,13 @@ def test_the_joined_window_has_the_running_loss_and_the_gradients_of_the_micro_b
     ref = {k: p.grad.clone() for k, p in model.named_parameters()}
     # one batch
     out = fuse_micro_batches(mbs, pad_id=PAD, multiple=8)
-    assert (WEIGHTS_KEY in out) == (kind == "cpt_ragged")
+    assert (WEIGHTS_KEY in out) == (kind != "sft") and ("packed_input_pos" in out) == (kind != "stacked")
     li = loss_inputs(out)
     model = hx.oracle_model(params, sd)
-    logits = model(tokens=li["tokens"], mask=_doc_mask(li["input_pos"]), input_pos=li["input_pos"])
+    if kind == "stacked":
+        logits = model(tokens=li["tokens"])
+    else:
+        logits = model(tokens=li["tokens"], mask=_doc_mask(li["input_pos"]), input_pos=li["input_pos"])
     logits = torch.cat(logits, dim=1) if isinstance(logits, list) else logits
     shifted = torch.hstack((li["labels"][..., 1:], torch.full_like(li["labels"][..., -1:], -100))).reshape(-1)
     nll = F.cross_entropy(logits.reshape(-1, logits.size(-1)).float(), shifted, ignore_index=-100, reduction="none")
@@ -146,6 +161,6 @@ def test_the_joined_window_has_the_running_loss_and_the_gradients_of_the_micro_b
     for k, p in model.named_parameters():
         err = float((p.grad - ref[k]).norm() / ref[k].norm())
         assert err <= 2e-5, (k, err)
-    if kind == "cpt_ragged":   # and the weights matter: without them the result is NOT the reference's
+    if kind != "sft":          # and the weights matter: without them the result is NOT the reference's
         plain = float(nll.detach().sum() / int((shifted != -100).sum())) * n
         assert abs(plain - running) > 1e-5 * abs(running)   # (small at a random init, where every token's loss is about log V)
