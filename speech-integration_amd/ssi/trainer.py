@@ -415,9 +415,9 @@ class Trainer:
             self.model.sync_this_backward = bool(sync_gradients)
         if on_gpu:
             self._arm_optimizer(n_valid, bool(sync_gradients))
-        if "packed_tokens" in batch:  # the prefetch thread dropped this batch's padding (ssi/data/unpad.py) or joined a window's micro-batches
+        if batch.get("packed_input_pos") is not None:  # the prefetch thread dropped the padding (ssi/data/unpad.py, ssi/data/window.py)
             self.unpadded_micro_batches += int(batch.get("micro_batches", 1))
-            self.fused_micro_batches += int(batch.get("micro_batches", 0))
+        self.fused_micro_batches += int(batch.get("micro_batches", 0))  # micro-batches that arrived joined into one batch (ssi/data/window.py)
         loss_batch = compute_loss(loss_inputs(batch), self.model, self.loss_fn) * n_valid  # mean over SHIFTED x UNSHIFTED count
         loss_batch.backward()
         if on_gpu:

@@ -248,6 +248,7 @@ def test_trainer_three_steps_match_cpu_step_oracle(tmp_path, dtype_name, tol, ra
         assert t.unpadded_micro_batches >= 4, t.unpadded_micro_batches
     else:
         assert t.unpadded_micro_batches == 0
+    assert t.fused_micro_batches == 6   # (round 5: each window's two micro-batches reach the model as one batch, ssi/data/window.py)
     assert os.path.exists(tmp_path / "ckpt" / "step_3" / "model.safetensors") and os.path.exists(tmp_path / "ckpt" / "training_state.pt")
     rec = t.wandb_logger.records
     assert [r["step"] for r in rec] == [1, 2, 3] and "dev_loss" in rec[-1] and np.isfinite(rec[-1]["dev_loss"])
