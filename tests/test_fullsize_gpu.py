@@ -306,6 +306,7 @@ def test_full_width_model_on_ragged_padded_micro_batches_matches_the_cpu_oracle(
             b["labels"][r, n:] = -100
         batches.append(b)
     batches[0]["labels"][2] = -100        # a row that contributes nothing
+    batches[1]["labels"][:, 0] = batches[1]["tokens"][:, 0]   # CPT-style rows (labels = tokens, column 0 included): unshifted != shifted count
     ref = OracleLlama(**params, rope_cache_len=1024)
     ref.load_state_dict(sd)
     ref.set_num_output_chunks(8)
@@ -360,6 +361,29 @@ def test_full_width_model_on_ragged_padded_micro_batches_matches_the_cpu_oracle(
         pad_rows = model._view("emb", None, model._flat_grad)[params["vocab_size"]:]
         assert float(pad_rows.abs().max()) == 0.0      # the rows that pad the table to whole tiles never receive a gradient
         grads[how] = {k: p.grad.float().cpu().clone() for k, p in model.named_parameters()}
+    # Round 5: the window's two micro-batches as ONE batch (ssi/data/window.py, the trainer's default): rows of both end to end, one forward /
+    # backward.  The reference gives every micro-batch its own weight (unshifted / shifted label count: 1 for the first micro-batch, 1.0014 for
+    # the CPT-style second) — carried per position, applied by the cross-entropy kernel per row.  Against the oracle's LOOP over the micro-batches.
+    from ssi.data.window import WEIGHTS_KEY, fuse_micro_batches
+    model.zero_grad(set_to_none=True)
+    joined = fuse_micro_batches(batches, pad_id=pad_id, padded_len=model.padded_seq_len, plan_fn=lambda ip: model.build_attn_plan(ip, force=True))
+    assert joined is not None and WEIGHTS_KEY in joined and "packed_attn_plan" in joined and joined["micro_batches"] == 2
+    w = joined[WEIGHTS_KEY]
+    assert len(set(w.flatten().tolist())) == 3 and 1e-4 < float(w.max() - w.min()) < 1e-2   # (two micro-batches + the tile tail's 1)
+    n = int((joined["labels"] != -100).sum())
+    assert n == n_total
+    got = compute_loss(loss_inputs({k: to_dev(v) for k, v in joined.items()}), model, CEWithChunkedOutputLoss())
+    (got * n).backward()
+    want_running = sum(wl * int((b["labels"] != -100).sum()) for wl, b in zip(want_loss, batches))
+    rel = abs(got.item() * n - want_running) / want_running
+    print(f"[ragged full-width, window as one batch] running loss {got.item() * n:.4f} vs the oracle's loop {want_running:.4f} (rel {rel:.2e})")
+    assert rel <= 2e-4
+    worst, worst_key = 0.0, None
+    for (k, p), (_, p2) in zip(model.named_parameters(), ref.named_parameters()):
+        err = float((p.grad.float().cpu() - p2.grad).norm() / p2.grad.norm())
+        worst, worst_key = max((worst, worst_key), (err, k))
+        assert err <= TOL_GRAD_BF16, f"window as one batch, {k}: relative gradient error {err}"
+    print(f"[ragged full-width, window as one batch] worst relative gradient error {worst:.2e} ({worst_key})")
     for a, b_ in zip(losses["padded"], losses["unpadded"]):
         # bf16 model: a row's attention outputs depend on where its keys fall in the 64-key tiles (fp32 sums in another order, then the bf16
         # rounding): the two losses sit 6e-6 .. 9e-5 from the fp32 oracle, on either side of it.  In fp32 the transform is exact to 1e-6

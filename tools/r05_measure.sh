@@ -1,11 +1,13 @@
 #!/bin/bash
-# usage (GPU box, repo root): bash tools/r05_measure.sh <tag> [headline]
+# usage (GPU box, repo root): bash tools/r05_measure.sh <tag> [headline | headline-only]   (headline-only: without the secondary lines)
 # Round 5: the secondary workloads of one box in ONE file, gpurun_out/<tag>_secondary.json — every line with the attention backward kernels it
 # ran (bench.py's "attention_backward": ssi_attn_last_dispatch) so that a reader sees which path a number came from.  With "headline" also the
 # judged artefacts of the headline (tools/refresh_profiles.sh: bench line with cpu_baseline, rocprofv3 kernel stats, FETCH / WRITE passes).
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-if [ "$2" = "headline" ]; then bash tools/refresh_profiles.sh $tag || exit 1; fi
+HL=0; if [ "$2" = "headline" ] || [ "$2" = "headline-only" ]; then HL=1; fi
+if [ $HL = 1 ]; then bash tools/refresh_profiles.sh $tag || exit 1; fi
+if [ "$2" != "headline-only" ]; then
 run() { name=$1; shift; python bench.py --no-cpu-baseline "$@" > gpurun_out/${tag}_sec_${name}.json 2>/dev/null; echo "$name rc=$?"; }
 run headline
 run dsus8192 --n-dsus 8192
@@ -35,7 +37,8 @@ for f in sorted(glob.glob("gpurun_out/${tag}_sec_*.json")):
     os.remove(f)
 json.dump(out, open("gpurun_out/${tag}_secondary.json", "w"), indent=1)
 PY
-if [ "$2" = "headline" ]; then
+fi
+if [ $HL = 1 ]; then
 # per-kernel counters (three separate --pmc passes, never combined with trace domains other than the kernel trace): the headline's table, and the
 # attention kernels of the right-padded workload (document-aware forms of the pipelined backward)
 CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-timing"
