@@ -19,8 +19,9 @@ for any micro-batch, which gives ``sum_m mean_m u_m``), and none at all when the
 weight as an additive term of its exponent (``ssi_ce_fwd_weighted``): free.
 
 Not fused (the micro-batches then run one by one as before): windows that would exceed ``max_tokens`` are cut into the fewest runs of
-consecutive micro-batches that fit (each run is one forward/backward; the last one closes the window); batches that are not plain right-padded
-host ``tokens`` / ``labels`` pairs; a micro-batch without any shifted valid label (its mean is 0/0 in the reference and stays so here)."""
+consecutive micro-batches that fit (each run is one forward/backward; the last one closes the window); batches that are neither plain right-padded
+host ``tokens`` / ``labels`` pairs nor packs of one length (``ssi/data/packed.py``: those are stacked row by row, documents and left shift of
+every row as they were); a micro-batch without any shifted valid label (its mean is 0/0 in the reference and stays so here)."""
 
 from __future__ import annotations
 
@@ -40,6 +41,15 @@ def _plain_padded(batch: Any) -> bool:
     t, l = batch.get("tokens"), batch.get("labels")
     return (torch.is_tensor(t) and torch.is_tensor(l) and not t.is_cuda and not l.is_cuda and t.dim() == 2 and t.shape == l.shape
             and all(batch.get(k) is None for k in ("input_pos", "mask", "encoder_input", "encoder_mask")) and PACKED_KEYS[0] not in batch)
+
+
+def _packed_rows(batch: Any) -> bool:
+    """A batch that arrives packed (``ssi/data/packed.py``: ``tokens`` / ``labels`` / ``input_pos`` of one shape, host tensors, no mask)."""
+    if not isinstance(batch, dict):
+        return False
+    t, l, p = batch.get("tokens"), batch.get("labels"), batch.get("input_pos")
+    return (all(torch.is_tensor(x) and not x.is_cuda and x.dim() == 2 for x in (t, l, p)) and t.shape == l.shape == p.shape
+            and all(batch.get(k) is None for k in ("mask", "encoder_input", "encoder_mask", "attn_plan")) and PACKED_KEYS[0] not in batch)
 
 
 def kept_lengths(labels: torch.Tensor, ignore_index: int) -> torch.Tensor:
@@ -62,12 +72,30 @@ def fuse_micro_batches(batches: list[dict[str, Any]], *, pad_id: int = 0, ignore
     the rows the model runs, ``padded_len(B, S)`` per sequence — are stacked as plain rows ``[sum B_m, S]`` instead: no ``packed_input_pos``,
     the model's plain causal path (the headline's kernels), labels untouched (a row's column 0 is never a target, its last position's target
     is ignored by the shift)."""
-    if len(batches) < 2 or not all(_plain_padded(b) for b in batches):
+    if len(batches) < 2:
+        return None
+    packs = all(_packed_rows(b) for b in batches) and len({tuple(b["tokens"].shape[1:]) for b in batches}) == 1
+    if not packs and not all(_plain_padded(b) for b in batches):
         return None
     u = [int((b["labels"] != ignore_index).sum()) for b in batches]
     s = [int((b["labels"][:, 1:] != ignore_index).sum()) for b in batches]
     if min(s) == 0:
         return None
+    if packs:  # packs of one length: their rows stacked, every row keeps its documents (input_pos) and its own left shift
+        U, S = sum(u), sum(s)
+        out = {"tokens": torch.cat([b["tokens"].reshape(1, -1) for b in batches], dim=1),
+               "labels": torch.cat([b["labels"].reshape(1, -1) for b in batches], dim=1),
+               "max_seq_len": int(batches[0]["tokens"].shape[1]), "micro_batches": len(batches),
+               "packed_tokens": torch.cat([b["tokens"] for b in batches], dim=0), "packed_labels": torch.cat([b["labels"] for b in batches], dim=0),
+               "packed_input_pos": torch.cat([b["input_pos"] for b in batches], dim=0)}
+        if not all(u[m] * s[0] == u[0] * s[m] for m in range(len(batches))):
+            out[WEIGHTS_KEY] = torch.cat([torch.full(b["tokens"].shape, (u[m] / s[m]) * (S / U), dtype=torch.float32)
+                                          for m, b in enumerate(batches)], dim=0)
+        if plan_fn is not None:
+            plan = plan_fn(out["packed_input_pos"])
+            if plan is not None:
+                out[PLAN_KEY] = plan
+        return out
     keeps = [kept_lengths(b["labels"], ignore_index).tolist() for b in batches]
     total = sum(sum(k) for k in keeps)
     t_packed = -(-total // multiple) * multiple
@@ -143,12 +171,13 @@ def fused_windows(indexed_batches: Iterable[tuple[int, dict[str, Any]]], window:
 
     def flush() -> Iterator[tuple[int, dict[str, Any]]]:
         group, held[:] = list(held), []
-        whole = len(group) == window and group[0][0] % window == 0 and all(_plain_padded(b) for _, b in group)
+        packs = all(_packed_rows(b) for _, b in group)
+        whole = len(group) == window and group[0][0] % window == 0 and (packs or all(_plain_padded(b) for _, b in group))
         if not whole:
             for i, b in group:
                 yield i, single(b)
             return
-        sizes = [int(kept_lengths(b["labels"], ignore_index).sum()) for _, b in group]
+        sizes = [int(b["tokens"].numel()) if packs else int(kept_lengths(b["labels"], ignore_index).sum()) for _, b in group]
         for a, z in _runs_that_fit(sizes, max_tokens):
             fused = fuse_micro_batches([b for _, b in group[a:z]], **fuse_kwargs) if z - a > 1 else None
             if fused is not None:

@@ -541,10 +541,13 @@ def test_full_size_step_properties():
     assert abs(le - l1) <= 1e-6 * abs(l1)                                            # (4)
 
 
+@pytest.mark.parametrize("ga", [1, 2])
 @pytest.mark.parametrize("packed", [False, True])
-def test_trainer_on_sft_samples_from_a_json_file_and_a_tokenizer_file(tmp_path, monkeypatch, packed):
+def test_trainer_on_sft_samples_from_a_json_file_and_a_tokenizer_file(tmp_path, monkeypatch, packed, ga):
     """The data front end feeding the step: speech units + transcripts in a local json file, a (toy) extended tokenizer.model,
-    ``setup_sft_data`` -> padded or packed batches -> Trainer.train(); per-step losses against the CPU step oracle on the same batches."""
+    ``setup_sft_data`` -> padded or packed batches -> Trainer.train(); per-step losses against the CPU step oracle on the same batches.
+    ``ga = 2``: the two batches are one accumulation window, which reaches the model as ONE batch (``ssi/data/window.py``: padded rows end to
+    end without their padding, packs stacked row by row) — against the oracle's loop over the two micro-batches."""
     import json
     from oracle import step_oracle
     from oracle.llama_oracle import OracleCEWithChunkedOutputLoss, OracleLlama
@@ -560,8 +563,8 @@ def test_trainer_on_sft_samples_from_a_json_file_and_a_tokenizer_file(tmp_path, 
     dump_tiktoken_bpe(toy_ranks(), tmp_path / "tokenizer.model")
     (tmp_path / "train.jsonl").write_text("\n".join(json.dumps(r) for r in ROWS))
     cfg = compose(os.path.join(PKG, "conf"), "sft", [
-        "data=sft/mls-speechtokenizer-rvq_0", "dtype=fp32", "max_steps=2", "gradient_accumulation_steps=1", "tokenizer.max_seq_len=128",
-        "eval_steps=2", "save_steps=100", "lr_scheduler.num_warmup_steps=1", "optimizer.lr=1e-3", f"output_dir={tmp_path}",
+        "data=sft/mls-speechtokenizer-rvq_0", "dtype=fp32", f"max_steps={2 // ga}", f"gradient_accumulation_steps={ga}", "tokenizer.max_seq_len=128",
+        f"eval_steps={2 // ga}", "save_steps=100", "lr_scheduler.num_warmup_steps=1", "optimizer.lr=1e-3", f"output_dir={tmp_path}",
         f"checkpointer.output_dir={tmp_path}/ckpt", f"checkpointer.checkpoint_dir={tmp_path}/none", "checkpointer.allow_random_init=true", "data.train.shuffle=false",
         f"tokenizer.path={tmp_path}/tokenizer.model", "tokenizer.verbose=false",
         "data.train.dataset.source=json", "data.dev.dataset.source=json", "data.train.dataset.n_samples=null", "data.dev.dataset.n_samples=4",
@@ -583,16 +586,17 @@ def test_trainer_on_sft_samples_from_a_json_file_and_a_tokenizer_file(tmp_path, 
     batches = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()} for b in itertools_islice(t.data_train, 2)]
     assert ("input_pos" in batches[0]) == packed and batches[0]["tokens"].shape[0] == 2
     t.train()
-    assert t.global_step == 2 and len(t._loss_log) == 2
+    assert t.global_step == 2 // ga and len(t._loss_log) == 2 // ga and t.fused_micro_batches == (2 if ga == 2 else 0)
     ref = OracleLlama(**t._llama_config.parameters, rope_cache_len=256)
     ref.load_state_dict(sd0)
     ref.set_num_output_chunks(8)
     opt = torch.optim.AdamW(ref.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
-    sched = get_cosine_schedule_with_warmup(opt, num_warmup_steps=1, num_training_steps=2, num_cycles=0.5)
+    sched = get_cosine_schedule_with_warmup(opt, num_warmup_steps=1, num_training_steps=2 // ga, num_cycles=0.5)
     if packed:
         from ssi.data import packed_block_causal_mask
         batches = [{**b, "mask": packed_block_causal_mask(b["seq_lens"])} for b in batches]
-    losses = step_oracle.run_steps(ref, OracleCEWithChunkedOutputLoss(), [batches[0:1], batches[1:2]], opt, sched)
+    windows = [batches[0:1], batches[1:2]] if ga == 1 else [batches[0:2]]
+    losses = step_oracle.run_steps(ref, OracleCEWithChunkedOutputLoss(), windows, opt, sched)
     print("gpu", t._loss_log, "cpu", losses)
     for a, b in zip(t._loss_log, losses):
         assert abs(a - b) <= 2e-5 * abs(b)

@@ -93,6 +93,32 @@ def test_equal_ratios_need_no_weights_and_what_cannot_be_joined_is_declined():
     assert out["packed_attn_plan"] == "plan" and seen[0] is out["packed_input_pos"] and loss_inputs(out)["attn_plan"] == "plan"
 
 
+def test_packs_of_one_length_are_stacked_row_by_row():
+    def pack(seed, lens):
+        b = _ragged(2, 48, [48, 48], seed=seed)
+        b["input_pos"] = torch.cat([torch.arange(n) for n in lens])[None].expand(2, 48).clone()
+        b["seq_lens"] = [torch.tensor(lens)] * 2
+        return b
+    mbs = [pack(1, [20, 28]), pack(2, [48]), pack(3, [5, 40, 3])]
+    mbs[1]["labels"][:, :7] = -100                                           # another ratio unshifted / shifted
+    seen = []
+    out = fuse_micro_batches(mbs, pad_id=PAD, multiple=16, plan_fn=lambda ip: seen.append(ip) or "plan")
+    assert out["packed_tokens"].shape == (6, 48) and torch.equal(out["packed_input_pos"], torch.cat([b["input_pos"] for b in mbs]))
+    assert torch.equal(out["packed_labels"], torch.cat([b["labels"] for b in mbs])) and out["micro_batches"] == 3 and out["max_seq_len"] == 48
+    assert out["packed_attn_plan"] == "plan" and seen[0] is out["packed_input_pos"] and out["tokens"].shape == (1, 288)
+    w = out[WEIGHTS_KEY]
+    assert w.shape == (6, 48) and float(w[2, 0]) < float(w[0, 0]) == float(w[5, 47])
+    assert set(loss_inputs(out)) == {"tokens", "labels", "input_pos", "attn_plan", "loss_weights"}
+    assert fuse_micro_batches([mbs[0], _ragged(2, 48, [48, 30], seed=4)], pad_id=PAD) is None            # a pack and a padded batch: not joined
+    other = pack(5, [48])
+    other = {k: (v[:, :32] if torch.is_tensor(v) else v) for k, v in other.items()}
+    assert fuse_micro_batches([mbs[0], other], pad_id=PAD) is None                                       # packs of two lengths
+    got = list(fused_windows(((i, pack(i, [48])) for i in range(4)), 2, max_tokens=10_000, single=lambda b: b, pad_id=PAD, multiple=16))
+    assert [(i, b["micro_batches"], tuple(b["packed_tokens"].shape)) for i, b in got] == [(1, 2, (4, 48)), (3, 2, (4, 48))]
+    got = list(fused_windows(((i, pack(i, [48])) for i in range(4)), 4, max_tokens=200, single=lambda b: b, pad_id=PAD, multiple=16))
+    assert [(i, b["micro_batches"]) for i, b in got] == [(1, 2), (3, 2)]                                 # 96 positions per pack: two fit into 200
+
+
 def test_a_stream_of_micro_batches_becomes_one_batch_per_window():
     mk = lambda i, lens=(30, 12): _ragged(2, 32, list(lens), seed=i)  # noqa: E731
     kw = dict(pad_id=PAD, multiple=16)
