@@ -4,16 +4,17 @@ The reference accumulates gradients over ``gradient_accumulation_steps`` micro-b
 loop: ``/root/reference/ssi/trainer.py:385-424``) of 2 rows (SFT, ``conf/data/_sft_base.yaml:21``) or 16 (CPT): micro-batches exist to fit the
 activations of a step into the memory of the GPU it was written for.  An MI355X holds the activations of the whole window (288 GB), and a
 2 x 2048 micro-batch fills its 256 CUs badly: 64-tile GEMM grids, four weight-gradient passes with a quarter of the K each.  So the micro-batches
-of a window are collated as usual, and then — on the host, in the prefetch thread — laid end to end as one packed sequence, exactly as
-``ssi.data.unpad`` does with the rows of one batch: every row a document of the block-causal attention with its own positions, no padding.  One
-forward, one backward, one optimizer step: the window's gradient is the same sum.
+of a window are collated as usual, and then — on the host, in the prefetch thread — joined: ragged rows laid end to end as one packed sequence,
+exactly as ``ssi.data.unpad`` does with the rows of one batch (every row a document of the block-causal attention with its own positions, no
+padding); full rows of one width stacked as plain rows; packs of one length stacked row by row.  One forward, one backward, one optimizer step:
+the window's gradient is the same sum.
 
 What has to be kept is the reference's normalisation.  Per micro-batch m it adds ``mean_m x u_m`` to the running loss (``trainer.py:393-395``),
 where ``mean_m`` is the cross-entropy over the micro-batch's ``s_m`` SHIFTED valid labels (``ssi/loss.py:16-22``) and ``u_m`` its count of
 UNSHIFTED ones, and divides the summed gradients by ``U = sum u_m`` at the boundary (``trainer.py:404``): every token's term carries the weight
 ``u_m / s_m`` of its micro-batch.  The two counts differ by the rows whose column-0 label is valid (all rows in CPT, none in SFT, where BOS is
-masked), so the weight is the same for every micro-batch whenever they hold equally many valid labels per row-with-a-valid-first-label — and
-differs by a few 1e-4 between ragged CPT micro-batches.  The fused batch therefore carries one fp32 weight per position,
+masked), so the weights are equal in SFT and between CPT micro-batches of full rows, and differ by a few 1e-4 between ragged CPT
+micro-batches.  The joined batch therefore carries one fp32 weight per position,
 ``w = (u_m / s_m) (S / U)`` with ``S = sum s_m`` (``loss_weights``: ``fused_loss`` returns ``sum w nll / S``, the trainer multiplies by ``U`` as
 for any micro-batch, which gives ``sum_m mean_m u_m``), and none at all when the ratios are equal.  The cross-entropy kernel applies the
 weight as an additive term of its exponent (``ssi_ce_fwd_weighted``): free.
