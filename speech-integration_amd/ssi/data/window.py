@@ -161,11 +161,13 @@ def _runs_that_fit(sizes: list[int], max_tokens: int) -> list[tuple[int, int]]:
 
 
 def fused_windows(indexed_batches: Iterable[tuple[int, dict[str, Any]]], window: int, *, max_tokens: int,
-                  single: Optional[Callable[[dict[str, Any]], dict[str, Any]]] = None, **fuse_kwargs: Any) -> Iterator[tuple[int, dict[str, Any]]]:
+                  single: Optional[Callable[[dict[str, Any]], dict[str, Any]]] = None, partial_windows: bool = False,
+                  **fuse_kwargs: Any) -> Iterator[tuple[int, dict[str, Any]]]:
     """``(index of the LAST micro-batch it holds, batch)`` pairs from ``(index, micro-batch)`` pairs: the micro-batches of every accumulation
     window (indices ``k window .. (k + 1) window - 1``) joined into as few batches as ``max_tokens`` allows.  A micro-batch that stays alone goes
     through ``single`` (the trainer: ``unpad_batch``).  A window the stream enters in its middle (it cannot, after ``resume_position``) or leaves
-    early is passed through unfused."""
+    early is passed through unfused — unless ``partial_windows`` (the dev-set loss, ``ssi/eval.py``: there a "window" is just a group of
+    batches whose ``loss_b x n_b`` terms are summed, and the last group may be short)."""
     ignore_index = fuse_kwargs.get("ignore_index", CROSS_ENTROPY_IGNORE_IDX)
     single = single or (lambda b: b)
     held: list[tuple[int, dict[str, Any]]] = []
@@ -173,7 +175,7 @@ def fused_windows(indexed_batches: Iterable[tuple[int, dict[str, Any]]], window:
     def flush() -> Iterator[tuple[int, dict[str, Any]]]:
         group, held[:] = list(held), []
         packs = all(_packed_rows(b) for _, b in group)
-        whole = len(group) == window and group[0][0] % window == 0 and (packs or all(_plain_padded(b) for _, b in group))
+        whole = (partial_windows or (len(group) == window and group[0][0] % window == 0)) and (packs or all(_plain_padded(b) for _, b in group))
         if not whole:
             for i, b in group:
                 yield i, single(b)

@@ -513,7 +513,10 @@ class Trainer:
     def _evaluate(self) -> float:
         return compute_dataset_loss(self.model, self.data_dev, self.loss_fn,
                                     epoch=self.global_step // self.geometry.steps_per_epoch, global_step=self.global_step,
-                                    steps_per_epoch=self.geometry.steps_per_epoch, device=self.device)
+                                    steps_per_epoch=self.geometry.steps_per_epoch, device=self.device,
+                                    join_batches=int(self.cfg.get("eval_join_batches", 16) or 0) if self.cfg.get("padding_free", True) else 0,
+                                    max_tokens=int(self.cfg.get("fused_window_max_tokens", 32768)), pad_id=int(getattr(self.tokenizer, "pad_id", 0) or 0),
+                                    prefetch=int(self.cfg.get("prefetch_batches", 2) or 0))
 
     def _log_metrics(self, epoch: int, iter_idx: int, loss_to_log: float) -> None:
         """One console line per optimizer step; the metric record (same keys as the reference logs to W&B, ``trainer.py:440-475``) every

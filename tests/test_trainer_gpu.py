@@ -121,9 +121,24 @@ def test_dev_loss_matches_the_oracle(tmp_path):
             n_b = int((b["labels"] != -100).sum())                                    # UNSHIFTED count (ssi/eval.py:33-38)
             num += float(oracle_loss(b, ref, OracleCEWithChunkedOutputLoss())) * n_b
             den += n_b
-    got = t._evaluate()
-    print(f"dev loss {got:.7f} vs oracle {num / den:.7f}")
-    assert abs(got - num / den) <= 1e-5 * abs(num / den)
+    # Round 5: by default the dev batches reach the model several at a time as one batch (ssi/eval.py, eval_join_batches: 16 — here all four,
+    # the one-row last batch included; with 3: a group of three and a lone batch); the sum of loss_b x n_b is kept by per-token weights
+    from ssi.data import window
+    joined_sizes = []
+    real = window.fuse_micro_batches
+    window.fuse_micro_batches = lambda bs, **k: (joined_sizes.append(len(bs)), real(bs, **k))[1]
+    try:
+        got = t._evaluate()
+        t.cfg.eval_join_batches = 3
+        got3 = t._evaluate()
+        t.cfg.eval_join_batches = 0
+        got0 = t._evaluate()
+    finally:
+        window.fuse_micro_batches = real
+    assert joined_sizes == [4, 3]
+    print(f"dev loss {got:.7f} (joined) {got3:.7f} (in threes) {got0:.7f} (batch by batch) vs oracle {num / den:.7f}")
+    for value in (got, got3, got0):
+        assert abs(value - num / den) <= 1e-5 * abs(num / den)
     assert t.model.training                                                           # back in training mode afterwards
     # the value logged by the training loop at an eval step is that same number
     t2 = _trainer(tmp_path, "dev2", overrides=["max_steps=1", "eval_steps=1", "save_steps=1", "optimizer.lr=0.0",

@@ -141,6 +141,11 @@ def test_a_stream_of_micro_batches_becomes_one_batch_per_window():
     odd = {**mk(5), "input_pos": torch.arange(32).expand(2, 32)}
     got = list(fused_windows(((i, odd if i == 5 else mk(i)) for i in range(8)), 4, max_tokens=10_000, single=single, **kw))
     assert [(i, b.get("micro_batches", 1)) for i, b in got] == [(3, 4), (4, 1), (5, 1), (6, 1), (7, 1)]
+    # the dev-set loss joins whatever comes, a short last group included (ssi/eval.py)
+    got = list(fused_windows(((i, mk(i)) for i in range(7)), 3, max_tokens=10_000, partial_windows=True, **kw))
+    assert [(i, b.get("micro_batches", 1)) for i, b in got] == [(2, 3), (5, 3), (6, 1)]
+    got = list(fused_windows(((i, mk(i)) for i in range(1, 6)), 3, max_tokens=10_000, partial_windows=True, **kw))
+    assert [(i, b.get("micro_batches", 1)) for i, b in got] == [(2, 2), (5, 3)]
     # the single-batch path is the trainer's unpad_batch
     got = list(fused_windows(((i, mk(i)) for i in range(2, 4)), 4, max_tokens=10_000,
                              single=lambda b: unpad_batch(b, pad_id=PAD, multiple=16, min_saving=0.0), **kw))
