@@ -152,6 +152,52 @@ def test_a_stream_of_micro_batches_becomes_one_batch_per_window():
     assert all("packed_tokens" in b and "micro_batches" not in b for _, b in got)
 
 
+def _pair_values(tokens, labels, input_pos=None):
+    """A stand-in for the per-token loss that depends on exactly what a decoder's loss term depends on at the level the joining can get wrong:
+    the (token, target) pair and the token's position in its document."""
+    shifted = torch.hstack((labels[..., 1:], torch.full_like(labels[..., -1:], -100)))
+    pos = input_pos if input_pos is not None else torch.arange(tokens.shape[1]).expand_as(tokens)
+    v = ((tokens * 7919 + shifted * 104729 + pos * 31) % 1009).double() / 1009.0 + 0.5
+    return torch.where(shifted != -100, v, torch.zeros_like(v)), shifted
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_windows_keep_the_loops_sum_of_mean_times_count(seed):
+    """Random windows (2-5 micro-batches, 1-4 rows each, ragged or full, masked prompts or none, rows without labels, one width or several,
+    padded batches or packs): ``sum_m mean_m x u_m`` of the loop == ``(sum w v / S) x U`` of the joined batch, in float64, whatever form the
+    joining takes — with a stand-in for the per-token loss that sees the (token, target) pair and the position in the document."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    n_mb, one_width, full_rows, packs = r(2, 5), r(0, 1), r(0, 3) == 0, r(0, 4) == 0
+    width = r(8, 40)
+    mbs = []
+    for m in range(n_mb):
+        B, S = r(1, 4), (width if (one_width or packs) else r(8, 40))
+        lens = [S if full_rows else r(2, S) for _ in range(B)]
+        b = _ragged(B, S, lens, seed=seed * 10 + m, prompt=r(0, 3))
+        if r(0, 5) == 0 and B > 1:
+            b["labels"][0] = -100
+        if packs:   # rows as packs: documents inside, input_pos restarting
+            cuts = sorted({0, *(r(1, S - 1) for _ in range(r(0, 2)))})
+            b["input_pos"] = torch.cat([torch.arange(z - a) for a, z in zip(cuts, cuts[1:] + [S])])[None].expand(B, S).clone()
+        mbs.append(b)
+    if any(int((b["labels"][:, 1:] != -100).sum()) == 0 for b in mbs):
+        assert fuse_micro_batches(mbs, pad_id=PAD, multiple=8) is None
+        return
+    running, U = 0.0, 0
+    for b in mbs:
+        v, shifted = _pair_values(b["tokens"], b["labels"], b.get("input_pos"))
+        u = int((b["labels"] != -100).sum())
+        running, U = running + float(v.sum() / int((shifted != -100).sum())) * u, U + u
+    out = fuse_micro_batches(mbs, pad_id=PAD, multiple=8)
+    li = loss_inputs(out)
+    v, shifted = _pair_values(li["tokens"], li["labels"], li.get("input_pos"))
+    w = li["loss_weights"].double() if "loss_weights" in li else torch.ones_like(v)
+    assert int((out["labels"] != -100).sum()) == U
+    got = float((w * v).sum() / int((shifted != -100).sum())) * U
+    assert abs(got - running) <= 2e-7 * abs(running), (got, running, sorted(out))   # (the weights are fp32)
+
+
 @pytest.mark.parametrize("kind", ["cpt_ragged", "sft", "stacked"])
 def test_the_joined_window_has_the_running_loss_and_the_gradients_of_the_micro_batch_loop_on_the_cpu_oracle(kind):
     params, _, _, seed = hx.CASES["tiny"]
