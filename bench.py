@@ -267,8 +267,9 @@ def through_trainer(args, result_out) -> int:
         key = f"grad_accum_{ga}" + ("" if joined else "_micro_batch_loop")
         tmp = tempfile.mkdtemp(prefix="ssi_through_trainer_")
         steps = args.warmup + args.steps
-        cfg = compose(os.path.join(PKG, "conf"), "sft", [
-            "data=sft/mls-hubert_large_ll60k-layer_22", f"dtype={args.dtype}", f"max_steps={steps}", f"gradient_accumulation_steps={ga}",
+        route = "cpt" if args.cpt else "sft"   # scripts/train_cpt.py composes conf/cpt.yaml the same way
+        cfg = compose(os.path.join(PKG, "conf"), route, [
+            f"data={route}/mls-hubert_large_ll60k-layer_22", f"dtype={args.dtype}", f"max_steps={steps}", f"gradient_accumulation_steps={ga}",
             f"tokenizer.max_seq_len={args.seq}", f"data.train.dataset.n_samples={steps * ga * args.batch}", "data.dev.dataset.n_samples=8",
             f"data.train.dataloader.batch_size={args.batch}", "eval_steps=1000000000", "save_steps=1000000000", f"output_dir={tmp}",
             f"checkpointer.output_dir={tmp}/ckpt", f"checkpointer.checkpoint_dir={tmp}/none", "checkpointer.allow_random_init=true",
@@ -289,6 +290,8 @@ def through_trainer(args, result_out) -> int:
             "tokens_per_second_per_gpu": sum(r["tokens_per_second_per_gpu"] for r in rec) / len(rec),
             "positions_per_second": sum(ga * args.batch * args.seq / d for d in dur) / len(dur),
             "ms_per_optimizer_step": 1e3 * sum(dur) / len(dur), "ms_per_micro_batch": 1e3 * sum(dur) / len(dur) / ga,
+            "median_ms_per_optimizer_step": 1e3 * sorted(dur)[len(dur) // 2], "ms_of_each_optimizer_step": [round(1e3 * d, 2) for d in dur],
+            "label_tokens_of_each_optimizer_step": [int(round(r["tokens_per_second_per_gpu"] * r["duration_step"])) for r in rec],
             "steps": len(rec), "warmup": args.warmup, "train_wall_s": wall, "last_loss": rec[-1]["loss"],
             "micro_batches_joined_into_one_batch_per_window": t.fused_micro_batches}
         if args.padded:  # ragged rows: the prefetch thread dropped the padding and built the attention backward's work plan beside each batch
@@ -304,7 +307,7 @@ def through_trainer(args, result_out) -> int:
         shutil.rmtree(tmp, ignore_errors=True)
     result_out.emit(json.dumps({"metric": "train_tokens_per_sec", "mode": "through_trainer", "unit": "tokens/s", "n_gpus": 1, "dtype": args.dtype,
                       "data": "synthetic", "higher_is_better": True,
-                      "config": {"workload": f"scripts/train_sft.py path: compose(conf/sft.yaml) -> Trainer.setup() -> Trainer.train(); Llama-3.2-1B "
+                      "config": {"workload": f"scripts/train_{route}.py path: compose(conf/{route}.yaml) -> Trainer.setup() -> Trainer.train(); Llama-3.2-1B "
                                              f"+{args.n_dsus} DSUs, seq_len={args.seq}, batch={args.batch}, prefetcher on, log_interval=1, 16 layers, "
                                              "random-init weights, MLS-shaped synthetic DSU sequences"
                                              + (", rows of unequal length right-padded by the collate function (the reference's batch format)" if args.padded else "")},
@@ -355,6 +358,7 @@ def main() -> int:
     ap.add_argument("--through-trainer", action="store_true",
                     help="secondary line: the workload through Trainer.setup()/train() (the scripts/train_sft.py path) at grad-accum 1 and 4; "
                          "one GPU.  Not the headline line.")
+    ap.add_argument("--cpt", action="store_true", help="with --through-trainer: the scripts/train_cpt.py path (conf/cpt.yaml; use --batch 16 --seq 768)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timing", action="store_true")
     args = ap.parse_args()
@@ -368,6 +372,8 @@ def main() -> int:
     result_out = _JsonOnlyStdout()  # from here on fd 1 is stderr; only result_out.emit() reaches the real stdout
     if args.through_trainer:
         return through_trainer(args, result_out)
+    from ssi.train_utils import limit_host_threads
+    limit_host_threads(world)  # torch's CPU thread pool within this process's CPU share (cpu_baseline sets its own count afterwards)
     local = int(os.environ.get("SSI_LOCAL_DEVICE", local))  # rehearsal hook: several ranks on one GPU (with SSI_DIST_BACKEND=gloo)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)

@@ -137,5 +137,15 @@ def ptr(t: torch.Tensor | None) -> int | None:
     return t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_CURRENT_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+_USE_RAW_STREAM = os.environ.get("SSI_RAW_STREAM", "1") != "0"  # (0: torch.cuda.current_stream() per launch, for in-run comparisons)
+
+
 def stream_ptr() -> int:
+    """The current HIP stream of the current device as an integer.  ``torch.cuda.current_stream()`` builds a Python Stream object behind a
+    device-index lookup — 20 us per call, once per launch: 12 of the 20 ms a backward of ~600 launches took on the host (cProfile of the trainer's
+    loop at 2 x 2048, ``profiles/LAB_NOTES.md`` round 5); the raw getter (what torch's own compiled code calls) is a C call."""
+    if _RAW_STREAM is not None and _CURRENT_DEVICE is not None and _USE_RAW_STREAM:
+        return _RAW_STREAM(_CURRENT_DEVICE())
     return torch.cuda.current_stream().cuda_stream

@@ -84,7 +84,12 @@ class _Arena:
             n *= s
         t = self.buf.get(name)
         if t is None or t.dtype != dtype or t.numel() < n:
-            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            # a buffer that has to GROW (ragged batches: the packed length differs from batch to batch) takes a quarter more than asked, so
+            # that a run reaches its largest batch in a few allocations instead of one per new length; fixed shapes never come here twice
+            grow = t is not None and t.dtype == dtype
+            if grow:
+                self.buf[name] = t = None  # (freed BEFORE the larger one is requested: the cached block may serve a smaller sibling)
+            t = torch.empty(max(n + n // 4 if grow else n, 1), dtype=dtype, device=self.device)
             self.buf[name] = t
         return t[:n].view(shape)
 

@@ -7,6 +7,7 @@ device-side result so the trainer can fold it into its single per-micro-batch sy
 from __future__ import annotations
 
 import logging
+import os
 from typing import Any
 
 import torch
@@ -18,6 +19,38 @@ from .constants import (CHECKPOINT_VERSION, CHECKPOINT_VERSION_KEY, CONSUMED_SAM
 from .llama_configs import ConfigLlama3_2
 
 LOGGER = logging.getLogger(__name__)
+
+
+def usable_cpus() -> int:
+    """CPUs this process may really use: the affinity mask and the cgroup's quota, not the host's count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def limit_host_threads(world_size: int = 1) -> int:
+    """Keep torch's intra-op thread pool within the process's CPU share.  torch sizes the pool by the HOST's cores (128 on a 256-thread box);
+    under a cgroup quota (16 CPUs on the GPU boxes here) the pool's threads, spinning behind every small CPU op of the data path (collate,
+    unpadding, the window's counts), burn the quota of a scheduling period in a few ms and the kernel freezes the WHOLE process — launch
+    thread included — for the rest of it: the GPU sat idle a third of the time in the trainer's loop at 2 x 2048 (stalls of 40-95 ms at random
+    places of the kernel trace, ``profiles/LAB_NOTES.md`` round 5).  The data path's ops are tiny: a few threads lose nothing.  An explicit
+    ``OMP_NUM_THREADS`` is respected.  Returns the thread count in force."""
+    if os.environ.get("OMP_NUM_THREADS"):
+        return torch.get_num_threads()
+    share = max(1, usable_cpus() // max(1, int(world_size)))
+    want = max(1, min(torch.get_num_threads(), share // 4, 8))
+    if want < torch.get_num_threads():
+        torch.set_num_threads(want)
+    return torch.get_num_threads()
 
 
 def _missing_keys(cfg) -> set:

@@ -44,7 +44,7 @@ from .lr_schedule import get_lr, setup_lr_scheduler
 from .metric_logging import WandBLoggerPatched as WandBLogger
 from .model import get_device, get_dtype, setup_llama3_2_1b
 from .optimizer import clip_grad_norm_, scale_grads, setup_optimizer
-from .train_utils import (count_token_types, count_token_types_async, get_token_type_ranges, resume_training_state,
+from .train_utils import (count_token_types, count_token_types_async, get_token_type_ranges, limit_host_threads, resume_training_state,
                           validate_resume_hparams, validate_train_cfg)
 
 __all__ = ["Trainer", "TrainingGeometry", "resume_position"]
@@ -197,6 +197,7 @@ class Trainer:
         self.device = get_device(self.cfg.device)
         self.dtype = get_dtype(self.cfg.dtype)
         self.world_size, self.rank = init_distributed(self.device)
+        limit_host_threads(self.world_size)  # (not in the reference: torch's CPU thread pool within this process's CPU share)
         self._setup_logging()
         self._setup_model()
         self._setup_tokenizer()

@@ -36,7 +36,9 @@ def _usable_cores() -> int:
 @pytest.fixture(scope="session", autouse=True)
 def _oracle_threads():
     import torch
-    torch.set_num_threads(min(_usable_cores(), 32))
+    n = min(_usable_cores(), 32)
+    torch.set_num_threads(n)
+    os.environ.setdefault("OMP_NUM_THREADS", str(n))  # explicit: Trainer.setup() (ssi.train_utils.limit_host_threads) then leaves the oracle's threads alone
     yield
 
 

@@ -282,3 +282,28 @@ def test_resume_position_skips_less_than_an_epoch(global_step):
     from ssi.trainer import resume_position
     _, skip = resume_position(global_step, 500, 4)
     assert 0 <= skip < 500 * 4 and skip % 4 == 0
+
+
+def test_host_threads_are_kept_within_the_cpu_share(monkeypatch):
+    """``limit_host_threads`` (``Trainer.setup()``): torch's intra-op pool is sized by the host's cores; under a cgroup quota its spinning threads
+    get the whole process frozen (round 5: a third of the GPU's time idle in the trainer's loop at 2 x 2048).  Lowered to a few threads unless
+    ``OMP_NUM_THREADS`` says otherwise; never raised; shared between the ranks of a node."""
+    import torch
+    from ssi import train_utils
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.setenv("OMP_NUM_THREADS", "7")
+        torch.set_num_threads(6)
+        assert train_utils.limit_host_threads() == 6                      # explicit setting: left alone
+        monkeypatch.delenv("OMP_NUM_THREADS")
+        monkeypatch.setattr(train_utils, "usable_cpus", lambda: 16)
+        assert train_utils.limit_host_threads() == 4                      # a quarter of a 16-CPU share
+        torch.set_num_threads(2)
+        assert train_utils.limit_host_threads() == 2                      # never raised
+        torch.set_num_threads(6)
+        assert train_utils.limit_host_threads(world_size=8) == 1          # 8 ranks share the node's 16 CPUs
+        monkeypatch.setattr(train_utils, "usable_cpus", lambda: 256)
+        torch.set_num_threads(6)
+        assert train_utils.limit_host_threads() == 6 and train_utils.usable_cpus() == 256
+    finally:
+        torch.set_num_threads(before)
