@@ -52,7 +52,11 @@ def run(joined: bool) -> dict:
     curve = [{"step": r["step"], "loss": r["loss"], "lr": r["lr"], "tokens_per_second_per_gpu": r["tokens_per_second_per_gpu"]} for r in rec]
     res = {"steps": steps, "batch": B, "grad_accum": ga, "ragged": args.ragged, "window_as_one_batch": bool(t.fused_micro_batches), "train_wall_s": wall,
            "first_loss": curve[0]["loss"], "last_loss": curve[-1]["loss"], "min_loss": min(c["loss"] for c in curve), "dev_loss_at_end": rec[-1].get("dev_loss"),
-           "tokens_total": rec[-1]["tokens_total"], "n_tokens": {k: v for k, v in rec[-1].items() if k.startswith("n_tokens.")}, "curve": curve}
+           "tokens_total": rec[-1]["tokens_total"], "n_tokens": {k: v for k, v in rec[-1].items() if k.startswith("n_tokens.")},
+           "max_memory_reserved_gib": round(torch.cuda.max_memory_reserved() / 2**30, 1),
+           "ms_per_step_percentiles_after_20_steps": (lambda d: {"p1": d[len(d) // 100], "p50": d[len(d) // 2], "p99": d[-max(1, len(d) // 100)], "max": d[-1]})(
+               sorted(round(1e3 * r["duration_step"], 1) for r in rec[20:])) if len(rec) > 40 else None,
+           "curve": curve}
     t.cleanup()
     del t
     torch.cuda.empty_cache()
