@@ -129,6 +129,10 @@ class Trainer:
         self.cfg = cfg
         self._pending_readbacks: list[tuple[Tensor, int]] = []  # (device row of a micro-batch's counts / loss / error counts, tokens in it)
         self._window_valid_dev: Tensor | None = None           # valid labels of the open window's micro-batches, summed on the device
+        self._window_valid_host: int | None = 0                # the same count from the host side of the batches (None: a batch came without one)
+        self._lagged: list[dict[str, Any]] = []                # windows whose read-back is on its way (``_optimizer_step_lagged``)
+        self._lag_buffers: list[Tensor] = []                   # page-locked buffers of finished read-backs, reused
+        self._t_last_arrival = 0.0                             # when the previous window's results were seen on the host
         for name in self._FILLED_BY_SETUP:
             setattr(self, name, None)
         for name, zero in self._COUNTERS.items():
@@ -142,6 +146,7 @@ class Trainer:
     # micro-batches (the reference blocks 7-8 times per micro-batch; rounds 1-2 of this trainer once).  Reading any of the three attributes
     # below fetches what is pending first — ONE device-to-host copy per window.
     def _read_back_window(self) -> None:
+        self._flush_lagged()  # earlier windows first: counters and log lines stay in order
         if not self._pending_readbacks:
             return
         pending, self._pending_readbacks = self._pending_readbacks, []
@@ -323,7 +328,7 @@ class Trainer:
     def train(self) -> None:
         """Run until ``cfg.max_steps`` optimizer steps have been taken, starting where ``global_step`` says (0, or a resume)."""
         self.optimizer.zero_grad()
-        self.t_train_start = self.t_step_start = time.perf_counter()
+        self.t_train_start = self.t_step_start = self._t_last_arrival = time.perf_counter()
         self._reset_step_accumulators()
         first_epoch, skip = resume_position(self.global_step, self.geometry.steps_per_epoch, self.cfg.gradient_accumulation_steps)
         if self._resume_rng_state is not None:
@@ -333,11 +338,14 @@ class Trainer:
             LOGGER.info("python / numpy / torch generator states restored from the training state")
         LOGGER.info(_to_yaml(self.cfg))
         self.wandb_logger.log_config(self.cfg)
-        for epoch in range(first_epoch, self.geometry.n_epochs):
-            self._train_epoch(epoch, skip if epoch == first_epoch else 0)
-            if self.global_step >= self.cfg.max_steps:
-                LOGGER.info(f"max_steps={self.cfg.max_steps} reached")
-                return
+        try:
+            for epoch in range(first_epoch, self.geometry.n_epochs):
+                self._train_epoch(epoch, skip if epoch == first_epoch else 0)
+                if self.global_step >= self.cfg.max_steps:
+                    LOGGER.info(f"max_steps={self.cfg.max_steps} reached")
+                    return
+        finally:
+            self._flush_lagged()
 
     def _epoch_batches(self, epoch: int, batches_to_skip: int):
         """``(index, batch)`` pairs of one epoch: the first ``usable_batches`` of the loader (whole accumulation windows only), minus
@@ -361,6 +369,8 @@ class Trainer:
                                     padded_len=kw["padded_len"])
         elif transform is not None:
             indexed = ((i, transform(b)) for i, b in indexed)
+        if self.device.type == "cuda" and self.grad_sync is None and self.cfg.get("lagged_readback", True):
+            indexed = self._with_host_label_counts(indexed)
         depth = int(self.cfg.get("prefetch_batches", 2) or 0)
         if self.device.type != "cuda" or depth <= 0:
             return indexed
@@ -373,6 +383,18 @@ class Trainer:
                 yield b
 
         return ((b.pop("_index"), b) for b in DevicePrefetcher(tagged(), self.device, depth=depth))
+
+    def _with_host_label_counts(self, indexed):
+        """``n_valid_host`` beside every batch whose labels are still on the host (they are, in the prefetch thread): the count of non-ignored
+        labels — all the accumulation boundary needs to know on the HOST (is the window empty?  what divides the gradients?) — without
+        waiting for the device (``_optimizer_step_lagged``)."""
+        ignore = self.loss_fn.ignore_index
+        for i, b in indexed:
+            labels = b.get("labels") if isinstance(b, dict) else None
+            if torch.is_tensor(labels) and not labels.is_cuda:
+                b = dict(b)
+                b["n_valid_host"] = int((labels != ignore).sum())
+            yield i, b
 
     def _host_batch_transform(self):
         """Right-padded batches lose their padding on the host, in the prefetch thread (``ssi.data.unpad``: exact, and the step's time then follows
@@ -415,6 +437,9 @@ class Trainer:
         if hasattr(self.model, "sync_this_backward"):
             self.model.sync_this_backward = bool(sync_gradients)
         if on_gpu:
+            n_host = batch.get("n_valid_host")
+            if self._window_valid_host is not None:
+                self._window_valid_host = None if n_host is None else self._window_valid_host + int(n_host)
             self._arm_optimizer(n_valid, bool(sync_gradients))
         if batch.get("packed_input_pos") is not None:  # the prefetch thread dropped the padding (ssi/data/unpad.py, ssi/data/window.py)
             self.unpadded_micro_batches += int(batch.get("micro_batches", 1))
@@ -460,6 +485,9 @@ class Trainer:
 
     def _optimizer_step(self, epoch: int, iter_idx: int) -> None:
         """Accumulation boundary (``trainer.py:397-424``): [all-reduce] -> scale -> clip -> AdamW -> LR -> counters."""
+        if (self._window_valid_host is not None and self._pending_readbacks and self.grad_sync is None
+                and self.cfg.get("lagged_readback", True)):
+            return self._optimizer_step_lagged(epoch, iter_idx)
         self._read_back_window()  # the window's one device-to-host copy: counts, losses and error counts of its micro-batches
         if self.grad_sync is not None:
             # one small collective: token count, running loss and the window's token-type counts (tokens_total is global, so the
@@ -488,6 +516,85 @@ class Trainer:
         self._reset_step_accumulators()
         if window_tokens > 0:
             self._maybe_save_checkpoint()
+
+    def _optimizer_step_lagged(self, epoch: int, iter_idx: int) -> None:
+        """The boundary without waiting for the device (one GPU; batches that came through ``_epoch_batches``).  What the host must know to go
+        on — is the window empty, what divides the gradients — is the count of valid labels, which the prefetch thread took from the host
+        tensors (``n_valid_host``).  Everything else the window left on the device (token-type counts, the loss for the log line, the
+        kernels' error counts) is copied back asynchronously and read one boundary later, so the host keeps launching: with a blocking
+        read-back the GPU idles 1.6 ms per optimizer step while the host does the boundary's bookkeeping and starts the next forward
+        (kernel trace at 8 x 2048, ``profiles/LAB_NOTES.md`` round 5).  The log line and the metric record of step k therefore appear when
+        step k + 1 closes — with the values of step k — except on steps that evaluate, save or end the run, which read back at once.  The
+        device's own count of valid labels is checked against the host's when it arrives."""
+        window_tokens = int(self._window_valid_host)
+        pending, self._pending_readbacks = self._pending_readbacks, []
+        rows = torch.stack([row for row, _ in pending])
+        host = next((b for b in self._lag_buffers if b.numel() >= rows.numel()), None)
+        if host is None:
+            host = torch.empty(max(rows.numel(), 256), dtype=rows.dtype, pin_memory=True)
+        else:
+            self._lag_buffers.remove(host)
+        host[:rows.numel()].view(rows.shape).copy_(rows, non_blocking=True)
+        arrived = torch.cuda.Event()
+        arrived.record()
+        entry: dict[str, Any] = {"arrived": arrived, "host": host, "shape": tuple(rows.shape), "positions": [n for _, n in pending],
+                                 "window_tokens": window_tokens, "epoch": epoch, "iter_idx": iter_idx, "applied": window_tokens > 0}
+        self._flush_lagged()  # the window before this one: its copy finished a whole step ago
+        now_due = False
+        if window_tokens > 0:
+            self._apply_window(window_tokens)
+            self.global_step += 1
+            self.consumed_samples += self.geometry.batch_size * self.cfg.gradient_accumulation_steps * self.world_size
+            self.tokens_train_total += window_tokens
+            entry.update(global_step=self.global_step, lr=get_lr(self.optimizer), tokens_total=self.tokens_train_total,
+                         max_seq_len_step=self.max_seq_len_step, grad_norm=self._grad_norm)  # (its clock is read when its copy arrives)
+            now_due = (self.global_step % self.cfg.eval_steps == 0 or self.global_step % self.cfg.save_steps == 0
+                       or self.global_step >= self.cfg.max_steps)
+        else:
+            LOGGER.warning("No non-ignored tokens in accumulation window; skipping optimizer step.")
+            if hasattr(self.optimizer, "cancel_overlap"):
+                self.optimizer.cancel_overlap()
+            self.optimizer.zero_grad(set_to_none=True)
+        self._lagged.append(entry)
+        self._reset_step_accumulators()
+        if now_due:
+            self._flush_lagged()  # (evaluation happens inside the log call, on the weights of exactly this step)
+        if window_tokens > 0:
+            self._maybe_save_checkpoint()
+
+    def _flush_lagged(self) -> None:
+        """Finish the boundaries whose read-back was left in flight, oldest first: counts into the totals, the kernels' error counts raised,
+        the device's label count checked against the host's, loss logged."""
+        while self._lagged:
+            e = self._lagged.pop(0)
+            e["arrived"].synchronize()
+            # the step's duration = from the arrival of the window before it to its own: the device's pace, not the host's (which runs ahead)
+            e["now"] = time.perf_counter()
+            e["step_seconds"], self._t_last_arrival = e["now"] - self._t_last_arrival, e["now"]
+            n_rows, width = e["shape"]
+            rows = e["host"][:n_rows * width].view(n_rows, width).tolist()
+            self._lag_buffers.append(e["host"])
+            kinds = list(self.token_type_ranges)
+            bad: defaultdict[str, int] = defaultdict(int)
+            loss_sum, n_valid_device = 0.0, 0
+            for host_row, n_positions in zip(rows, e["positions"]):
+                counts = {tt: int(c) for tt, c in zip(kinds + ["total"], host_row)}
+                for tt, c in counts.items():
+                    self._token_type_counts_total[tt] += c
+                n_valid_device += int(host_row[len(kinds) + 1])
+                loss_sum += float(host_row[-3])
+                bad["labels outside [0, vocab_size)"] += int(host_row[-2])
+                bad["token ids outside [0, vocab_size)"] += n_positions - sum(counts[tt] for tt in kinds)
+                bad["input_pos entries outside the RoPE table"] += int(host_row[-1])
+            self._raise_on_bad_inputs(bad)
+            if n_valid_device != e["window_tokens"]:
+                raise RuntimeError(f"the device counted {n_valid_device} valid labels in a window the host counted {e['window_tokens']} in")
+            if not e["applied"]:
+                continue
+            mean_loss = loss_sum / e["window_tokens"]
+            if self._loss_log is not None:
+                self._loss_log.append(mean_loss)
+            self._log_metrics(e["epoch"], e["iter_idx"], mean_loss, snapshot=e)
 
     def _apply_window(self, window_tokens: int) -> None:
         """Gradients of the window -> parameters: mean over the window's (global) unshifted token count, optional global-norm clip, AdamW,
@@ -519,35 +626,40 @@ class Trainer:
                                     max_tokens=int(self.cfg.get("fused_window_max_tokens", 32768)), pad_id=int(getattr(self.tokenizer, "pad_id", 0) or 0),
                                     prefetch=int(self.cfg.get("prefetch_batches", 2) or 0))
 
-    def _log_metrics(self, epoch: int, iter_idx: int, loss_to_log: float) -> None:
+    def _log_metrics(self, epoch: int, iter_idx: int, loss_to_log: float, snapshot: dict[str, Any] | None = None) -> None:
         """One console line per optimizer step; the metric record (same keys as the reference logs to W&B, ``trainer.py:440-475``) every
-        ``log_interval`` steps from rank 0; the dev loss joins it on steps that evaluate."""
+        ``log_interval`` steps from rank 0; the dev loss joins it on steps that evaluate.  ``snapshot``: the step's values as they were when
+        its window closed (``_optimizer_step_lagged`` logs a step after the next one has been launched); without one, the current state."""
+        if snapshot is None:
+            now = self._t_last_arrival = time.perf_counter()
+            snapshot = {"global_step": self.global_step, "window_tokens": self.num_tokens_step, "lr": get_lr(self.optimizer), "now": now,
+                        "step_seconds": now - self.t_step_start, "tokens_total": self.tokens_train_total,
+                        "max_seq_len_step": self.max_seq_len_step, "grad_norm": self._grad_norm}
+        step, type_counts = snapshot["global_step"], self._token_type_counts_total
         width = len(str(self.geometry.batches_per_epoch))
-        per_type = " | ".join(f"Tokens ({kind}): {n}" for kind, n in self.token_type_counts_total.items())
-        LOGGER.info(f"Epoch {epoch + 1:03d} | Iteration {iter_idx:0{width}d} / {self.geometry.batches_per_epoch} | Global Step {self.global_step} | "
-                    f"Loss: {loss_to_log:.4f} | Tokens (num_tokens_step): {self.num_tokens_step}" + (f" | {per_type}" if per_type else ""))
-        dev_loss = self._evaluate() if self.global_step % self.cfg.eval_steps == 0 else None
-        if self.global_step % self.cfg.log_interval:
+        per_type = " | ".join(f"Tokens ({kind}): {n}" for kind, n in type_counts.items())
+        LOGGER.info(f"Epoch {epoch + 1:03d} | Iteration {iter_idx:0{width}d} / {self.geometry.batches_per_epoch} | Global Step {step} | "
+                    f"Loss: {loss_to_log:.4f} | Tokens (num_tokens_step): {snapshot['window_tokens']}" + (f" | {per_type}" if per_type else ""))
+        dev_loss = self._evaluate() if step % self.cfg.eval_steps == 0 else None
+        if step % self.cfg.log_interval:
             return
-        now = time.perf_counter()
-        step_seconds = now - self.t_step_start
         ranks = self.world_size if (self.grad_sync is not None and self.world_size) else 1  # num_tokens_step is global under DP
         record: dict[str, Any] = {
             "loss": loss_to_log,
-            "lr": get_lr(self.optimizer),
-            "duration_step": step_seconds,
-            "tokens_per_second_per_gpu": self.num_tokens_step / step_seconds / ranks,
-            "tokens_total": self.tokens_train_total,
-            "train_clock_time": (self.wall_clock_offset + now - self.t_train_start) / 3600.0,
-            "max_seq_len_step": self.max_seq_len_step,
+            "lr": snapshot["lr"],
+            "duration_step": snapshot["step_seconds"],
+            "tokens_per_second_per_gpu": snapshot["window_tokens"] / snapshot["step_seconds"] / ranks,
+            "tokens_total": snapshot["tokens_total"],
+            "train_clock_time": (self.wall_clock_offset + snapshot["now"] - self.t_train_start) / 3600.0,
+            "max_seq_len_step": snapshot["max_seq_len_step"],
         }
-        record.update({f"n_tokens.{kind}": n for kind, n in self.token_type_counts_total.items()})
+        record.update({f"n_tokens.{kind}": n for kind, n in type_counts.items()})
         if self.cfg.clip_grad_norm is not None:
-            record["grad_norm"] = None if self._grad_norm is None else float(self._grad_norm)
+            record["grad_norm"] = None if snapshot["grad_norm"] is None else float(snapshot["grad_norm"])
         if dev_loss is not None:
             record["dev_loss"] = dev_loss
         if self.rank == 0:
-            self.wandb_logger.log_dict(record, step=self.global_step)
+            self.wandb_logger.log_dict(record, step=step)
 
     def _maybe_save_checkpoint(self) -> None:
         if self.global_step > 0 and self.global_step % self.cfg.save_steps == 0:
@@ -556,13 +668,14 @@ class Trainer:
 
     def _reset_step_accumulators(self) -> None:
         self.loss_running, self.num_tokens_step, self.max_seq_len_step = 0.0, 0, 0
-        self._window_valid_dev = None
+        self._window_valid_dev, self._window_valid_host = None, 0
         self.t_step_start = time.perf_counter()
 
     # === Checkpointing ===================================================================================================
     def save_checkpoint(self) -> None:
         """Model weights under ``step_N/`` plus ONE ``training_state.pt`` (schema v1, ``constants.py``) at the checkpoint root —
         rank 0 only: every rank holds the same weights and optimizer state."""
+        self._flush_lagged()  # (the cumulative token-type counts go into the training state)
         if self.rank != 0:
             return
         self.checkpointer.save_model_checkpoint(self.model.state_dict(), self.global_step)
