@@ -273,7 +273,8 @@ def through_trainer(args, result_out) -> int:
             f"tokenizer.max_seq_len={args.seq}", f"data.train.dataset.n_samples={steps * ga * args.batch}", "data.dev.dataset.n_samples=8",
             f"data.train.dataloader.batch_size={args.batch}", "eval_steps=1000000000", "save_steps=1000000000", f"output_dir={tmp}",
             f"checkpointer.output_dir={tmp}/ckpt", f"checkpointer.checkpoint_dir={tmp}/none", "checkpointer.allow_random_init=true",
-            f"speech.n_dsus={args.n_dsus}", f"fuse_accumulation_window={'true' if joined else 'false'}"]
+            f"speech.n_dsus={args.n_dsus}", f"fuse_accumulation_window={'true' if joined else 'false'}",
+            f"lagged_readback={'false' if os.environ.get('SSI_LAGGED_READBACK') == '0' else 'true'}"]
             + (["data.train.dataset.fixed_len=false"] if args.padded else []))
         resolve_n_dsus(cfg)
         t = Trainer(cfg)
