@@ -279,6 +279,65 @@ def test_a_window_run_as_one_batch_is_the_micro_batch_loop(tmp_path, config_name
     assert worst <= (2e-3 if dtype == "fp32" else 6e-2), worst   # (lr 2e-2 x 6 steps: AdamW moves every weight by up to 0.12)
 
 
+class _Edit:
+    """Wraps a loader: ``edit(i, batch)`` may change batch ``i`` in place."""
+
+    def __init__(self, loader, edit):
+        self.loader, self.dataset, self.edit = loader, loader.dataset, edit
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for i, b in enumerate(self.loader):
+            self.edit(i, b)
+            yield b
+
+
+@pytest.mark.parametrize("dtype,model", [("fp32", SMALL), ("bf16", MFMA_SMALL)])
+def test_the_boundary_that_does_not_wait_for_the_device_logs_what_the_waiting_one_logs(tmp_path, dtype, model):
+    """Round 5 (``lagged_readback``, default on; one GPU): at the accumulation boundary the host takes the window's label count from the host
+    side of the batches and goes on; the window's loss and counters come back a step later.  Against the boundary that waits
+    (``lagged_readback=false``): the same records (step numbers, losses bit for bit, learning rates, token totals and per-type counts),
+    the same weights; a window without any label is skipped the same way; a label outside the vocabulary still ends the run with the
+    kernels' error count."""
+    seq = 96 if dtype == "fp32" else 128
+    runs = {}
+    for name, extra in (("lagged", []), ("waiting", ["lagged_readback=false"])):
+        t = _trainer(tmp_path, name, dtype=dtype, model=model, seq=seq, overrides=["max_steps=5", "data.train.dataset.fixed_len=false", *extra])
+
+        def no_labels_in_window_two(i, b):   # batches 4 and 5 = the third window (grad-accum 2)
+            if i in (4, 5):
+                b["labels"][:] = -100
+        t.data_train = _Edit(t.data_train, no_labels_in_window_two)
+        lagged_calls, real = [], t._optimizer_step_lagged
+        t._optimizer_step_lagged = lambda *a, real=real, lagged_calls=lagged_calls: (lagged_calls.append(1), real(*a))[1]
+        t.train()
+        rec = t.wandb_logger.records
+        runs[name] = dict(losses=list(t._loss_log), w={k: v.detach().clone() for k, v in t.model.state_dict().items()}, lagged=len(lagged_calls),
+                          rec=[{k: r[k] for k in r if k not in ("duration_step", "tokens_per_second_per_gpu", "train_clock_time")} for r in rec],
+                          step=t.global_step, tokens=t.tokens_train_total, counts=dict(t.token_type_counts_total), consumed=t.consumed_samples)
+        assert all(r["duration_step"] > 0 for r in rec)
+        t.cleanup()
+        del t
+    a, b = runs["lagged"], runs["waiting"]
+    assert a["lagged"] == 6 and b["lagged"] == 0            # 5 optimizer steps + the skipped window
+    assert a["step"] == b["step"] == 5 and len(a["losses"]) == 5 and a["losses"] == b["losses"]
+    assert a["rec"] == b["rec"] and [r["step"] for r in a["rec"]] == [1, 2, 3, 4, 5]
+    assert (a["tokens"], a["counts"], a["consumed"]) == (b["tokens"], b["counts"], b["consumed"])
+    assert all(torch.equal(a["w"][k], b["w"][k]) for k in a["w"])
+    # a label outside the vocabulary: the kernels write zeros and count; the count ends the run when the window's results arrive
+    t = _trainer(tmp_path, "bad", dtype=dtype, model=model, seq=seq, overrides=["max_steps=5"])
+
+    def bad_label(i, b):
+        if i == 3:
+            b["labels"][0, 7] = 10_000_000
+    t.data_train = _Edit(t.data_train, bad_label)
+    with pytest.raises(IndexError, match="labels outside"):
+        t.train()
+    t.cleanup()
+
+
 def test_adamw_under_the_backward_skips_a_window_without_labels():
     """The factor 1 / 0 (a window whose labels are all ignored) reaches the kernel before the host has read the count back: the launches issued
     under the backward must change nothing by themselves — parameters, both moments and the step count stay as they were, the window after
