@@ -338,14 +338,12 @@ class Trainer:
             LOGGER.info("python / numpy / torch generator states restored from the training state")
         LOGGER.info(_to_yaml(self.cfg))
         self.wandb_logger.log_config(self.cfg)
-        try:
-            for epoch in range(first_epoch, self.geometry.n_epochs):
-                self._train_epoch(epoch, skip if epoch == first_epoch else 0)
-                if self.global_step >= self.cfg.max_steps:
-                    LOGGER.info(f"max_steps={self.cfg.max_steps} reached")
-                    return
-        finally:
-            self._flush_lagged()
+        for epoch in range(first_epoch, self.geometry.n_epochs):
+            self._train_epoch(epoch, skip if epoch == first_epoch else 0)
+            if self.global_step >= self.cfg.max_steps:
+                LOGGER.info(f"max_steps={self.cfg.max_steps} reached")
+                break
+        self._flush_lagged()  # (not in a finally: an exception on its way out should not be followed by a wait on the device)
 
     def _epoch_batches(self, epoch: int, batches_to_skip: int):
         """``(index, batch)`` pairs of one epoch: the first ``usable_batches`` of the loader (whole accumulation windows only), minus
