@@ -53,9 +53,11 @@ cat gpurun_out/${tag}_attn_pmc.md | cut -c1-260
 rm -rf gpurun_out/${tag}_fetch/*/*agent_info.csv gpurun_out/${tag}_pad_*/*/*agent_info.csv
 bash tools/r05_prof.sh ${tag}_padded --padded
 bash tools/r05_prof.sh ${tag}_packed --packed --seq 8192 --batch 2 --n-dsus 2048
-python bench.py --through-trainer --padded --steps 8 --warmup 3 > gpurun_out/${tag}_through_trainer_padded.json 2>/dev/null; echo "through-trainer padded rc=$?"
-python bench.py --through-trainer --steps 8 --warmup 3 > gpurun_out/${tag}_through_trainer.json 2>/dev/null; echo "through-trainer rc=$?"
+python bench.py --through-trainer --padded --steps 10 --warmup 3 > gpurun_out/${tag}_through_trainer_padded.json 2>/dev/null; echo "through-trainer padded rc=$?"
+python bench.py --through-trainer --steps 10 --warmup 3 > gpurun_out/${tag}_through_trainer.json 2>/dev/null; echo "through-trainer rc=$?"
 # the reference's default SFT geometry (2 rows x 2048, grad-accum 4) through the trainer: the window as one batch against the micro-batch loop
-python bench.py --through-trainer --batch 2 --steps 8 --warmup 3 > gpurun_out/${tag}_through_trainer_b2.json 2>/dev/null; echo "through-trainer b2 rc=$?"
-python bench.py --through-trainer --batch 2 --padded --steps 8 --warmup 3 > gpurun_out/${tag}_through_trainer_b2_padded.json 2>/dev/null; echo "through-trainer b2 padded rc=$?"
+python bench.py --through-trainer --batch 2 --steps 10 --warmup 3 > gpurun_out/${tag}_through_trainer_b2.json 2>/dev/null; echo "through-trainer b2 rc=$?"
+python bench.py --through-trainer --batch 2 --padded --steps 10 --warmup 3 > gpurun_out/${tag}_through_trainer_b2_padded.json 2>/dev/null; echo "through-trainer b2 padded rc=$?"
+python bench.py --through-trainer --cpt --batch 16 --seq 768 --steps 10 --warmup 3 > gpurun_out/${tag}_through_trainer_cpt_b16_s768.json 2>/dev/null; echo "through-trainer cpt rc=$?"
+python bench.py --through-trainer --cpt --batch 16 --seq 768 --padded --steps 10 --warmup 3 > gpurun_out/${tag}_through_trainer_cpt_b16_s768_padded.json 2>/dev/null; echo "through-trainer cpt padded rc=$?"
 fi
